@@ -1,0 +1,144 @@
+/*
+ * qln_evaluator.h -- C ABI of the MI355X-native batched NLP evaluator for the
+ * hybrid planar-quadruped landing problem.
+ *
+ * This is the drop-in boundary for the reference's evaluator path
+ *   src/moi.jl:1-33          (MOI.eval_objective / eval_objective_gradient /
+ *                             eval_constraint / eval_constraint_jacobian /
+ *                             jacobian_structure on HybridNLP)
+ *   src/costs.jl:6-34        (eval_f, grad_f!)
+ *   src/constraints.jl:145-158, 212-291   (eval_c!, jac_c!)
+ *   src/nlp.jl:13-87         (HybridNLP index maps, bounds, sizes)
+ * generalised from ONE problem to a batch of B independent landing problems.
+ * Plain pointers and sizes only; every entry point returns an int status
+ * (QLN_OK == 0, negative = error) and never throws or exits.  The Julia `ccall`
+ * veneer a maintainer would add is integration/julia/HybridNLPHIP.jl; the Python
+ * ctypes mirror used by the tests is quadruped_landing_amd/_lib.py.
+ *
+ * Layouts (all FP64, all offsets/strides in doubles):
+ *   Z     problem b at Z + b*z_stride, length n_nlp = 20N-5,
+ *         [x_1 u_1 x_2 u_2 ... x_{N-1} u_{N-1} x_N]           (src/nlp.jl:38-39,94-102)
+ *   c     problem b at c + c_off[b], length m_nlp(b) = 18N - k_trans(b) + 16, in the
+ *         reference's cinds order (src/nlp.jl:48-63): init 15 | term 14 | dyn 15(N-1) |
+ *         contact-init N | contact-other N-k_trans+1 | final-control 1 | clearance N
+ *   vals  problem b at vals + j_off[b], length nnz(b); block-COO of the reference's
+ *         jac_c! write-set, state-dependent entries first:
+ *           [ (N-1) step blocks, 15x20 column-major each            src/constraints.jl:186-198 ]
+ *           [ N clearance d/dtheta entries                          src/constraints.jl:269-273 ]
+ *           [ I(15) 15x15 col-major | I(15)[1:14,:] 14x15           src/constraints.jl:228-229 ]
+ *           [ 15(N-1) diagonal -1 of the -I(n) blocks               src/constraints.jl:200     ]
+ *           [ contact-init N ones | contact-other N-k_trans+1 ones  src/constraints.jl:235-256 ]
+ *           [ final-control 2 ones | clearance d/dyb N ones         src/constraints.jl:259-265 ]
+ *         The first 300(N-1)+N values depend on Z; the rest are constants and are
+ *         written only when QLN_JAC_WRITE_CONSTANTS is set (or once by
+ *         qln_jacobian_init_constants).
+ *   grad  same layout as Z.        f: one double per problem.
+ */
+#ifndef QLN_EVALUATOR_H
+#define QLN_EVALUATOR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLN_NX 15          /* state dim   (src/planar_quadruped.jl:25) */
+#define QLN_NU 5           /* control dim (src/planar_quadruped.jl:26) */
+#define QLN_NZ 20
+#define QLN_COST_STRIDE 41 /* Q[15] R[5] q[15] r[5] c  (src/quadratic_cost.jl:16-22) */
+
+#define QLN_OK 0
+#define QLN_ERR_INVALID_ARGUMENT (-1)
+#define QLN_ERR_HIP (-2)
+#define QLN_ERR_NO_DEVICE (-3)
+#define QLN_ERR_UNSUPPORTED (-4)
+
+/* flags for the Jacobian entry points */
+#define QLN_JAC_WRITE_CONSTANTS 1u
+
+typedef struct qln_handle qln_handle;
+
+/* PlanarQuadruped (src/planar_quadruped.jl:11-20) */
+typedef struct qln_model {
+    double g, mb, mf, lb, l1, l2;
+} qln_model;
+
+/* A batch of B landing problems with a common horizon N.  All pointers are HOST
+ * pointers; qln_create copies them to the device.  Mirrors the arguments of
+ * HybridNLP(model, obj, init_mode, k_trans, N, x0, xf) (src/nlp.jl:34-37). */
+typedef struct qln_batch_desc {
+    int32_t B;                /* problems */
+    int32_t N;                /* knot points per problem (>= 2) */
+    qln_model model;
+    const int32_t* k_trans;   /* [B], 1-based start index of mode 3, 1 <= k_trans <= N+1 */
+    const int32_t* init_mode; /* [B], 1 or 2 */
+    const double* x0;         /* [B][15] */
+    const double* xf;         /* [B][15] */
+    const double* cost;       /* [cost_batch][N][41] per-knot diagonal QuadraticCost (obj vector) */
+    int32_t cost_batch;       /* 1 = one table shared by all problems, or B */
+    int64_t z_stride;         /* doubles between consecutive problems in Z/grad; 0 -> n_nlp (dense) */
+    int32_t align;            /* c_off/j_off are rounded up to a multiple of this many doubles;
+                                 0 -> 16 (128 B).  j_off is always kept even. */
+} qln_batch_desc;
+
+typedef struct qln_dims {
+    int32_t B, N;
+    int32_t n_nlp;        /* 20N-5                           (src/nlp.jl:86) */
+    int32_t m_nlp_max;    /* max_b 18N - k_trans(b) + 16     (src/nlp.jl:87) */
+    int32_t nnz_max;      /* max_b nnz(b) */
+    int32_t nnz_dynamic;  /* 300(N-1)+N state-dependent values per problem */
+    int64_t z_stride;
+    int64_t z_total;      /* doubles to allocate for Z / grad */
+    int64_t c_total;      /* doubles to allocate for c */
+    int64_t j_total;      /* doubles to allocate for vals */
+} qln_dims;
+
+const char* qln_last_error(void);        /* thread-local message of the last failing call */
+const char* qln_version(void);
+
+/* Lifetime.  `device` is a HIP device ordinal. */
+int qln_create(const qln_batch_desc* desc, int device, qln_handle** out);
+int qln_destroy(qln_handle* h);
+/* All launches go to `hip_stream` (a hipStream_t; NULL = the default stream). */
+int qln_set_stream(qln_handle* h, void* hip_stream);
+int qln_synchronize(qln_handle* h);
+
+/* Sizes and index maps (num_primals/num_duals/cinds/lb/ub of src/nlp.jl:48-87). */
+int qln_get_dims(const qln_handle* h, qln_dims* out);
+int qln_get_offsets(const qln_handle* h, int64_t* c_off /*[B]*/, int64_t* j_off /*[B]*/);
+int qln_problem_dims(const qln_handle* h, int32_t b, int32_t* m_nlp, int32_t* nnz);
+int qln_constraint_index_ranges(const qln_handle* h, int32_t b, int32_t cinds[14]); /* 1-based [start,end] x 7 */
+int qln_constraint_bounds(const qln_handle* h, int32_t b, double* lb, double* ub);
+/* 0-based (row, col) of every entry of problem b's vals segment (MOI.jacobian_structure, src/moi.jl:31-33,
+ * restricted to the jac_c! write-set). */
+int qln_jacobian_structure(const qln_handle* h, int32_t b, int32_t* rows, int32_t* cols);
+
+/* Batched, device-pointer, stream-ordered (asynchronous) evaluation. */
+int qln_eval_objective(qln_handle* h, const double* Z, double* f);                 /* src/costs.jl:6-16  */
+int qln_eval_objective_gradient(qln_handle* h, const double* Z, double* grad);     /* src/costs.jl:23-34 */
+int qln_eval_constraint(qln_handle* h, const double* Z, double* c);                /* src/constraints.jl:145-158 */
+int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, uint32_t flags); /* :212-291 */
+/* The fused hot path: eval_c! and jac_c! of every knot of every problem in one launch. */
+int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags);
+int qln_jacobian_init_constants(qln_handle* h, double* vals);
+
+/* MOI mode: HOST pointers, synchronous (H2D, launch, D2H inside).  Same layouts. */
+int qln_eval_objective_host(qln_handle* h, const double* Z, double* f);
+int qln_eval_objective_gradient_host(qln_handle* h, const double* Z, double* grad);
+int qln_eval_constraint_host(qln_handle* h, const double* Z, double* c);
+int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* vals);
+/* Reference-compatible dense Jacobian of ONE problem (src/moi.jl:15-24): `jac` is a host,
+ * column-major m_nlp x n_nlp buffer; exactly the jac_c! write-set is assigned (explicit zeros of
+ * the identity blocks included), every other entry is left untouched.  `b` selects the problem. */
+int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const double* Z, double* jac);
+
+/* Measurement helper for bench.py: runs `warmup` + `iters` launches of the fused hot path on the
+ * handle's stream and returns each timed launch's duration from HIP events (milliseconds). */
+int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags,
+                                     int32_t warmup, int32_t iters, float* ms_each /*[iters]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

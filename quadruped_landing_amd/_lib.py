@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI in include/qln_evaluator.h (libqln_hip.so).
+
+There is no CPU fallback: if the HIP library is missing this module raises, and
+qln_create fails with QLN_ERR_NO_DEVICE when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqln_hip.so")
+
+QLN_OK = 0
+QLN_ERR_INVALID_ARGUMENT = -1
+QLN_ERR_HIP = -2
+QLN_ERR_NO_DEVICE = -3
+QLN_ERR_UNSUPPORTED = -4
+QLN_JAC_WRITE_CONSTANTS = 1
+
+NX, NU, NZ, COST_STRIDE = 15, 5, 20, 41
+
+
+class QlnModel(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("g", "mb", "mf", "lb", "l1", "l2")]
+
+
+class QlnBatchDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("N", C.c_int32),
+        ("model", QlnModel),
+        ("k_trans", C.POINTER(C.c_int32)),
+        ("init_mode", C.POINTER(C.c_int32)),
+        ("x0", C.POINTER(C.c_double)),
+        ("xf", C.POINTER(C.c_double)),
+        ("cost", C.POINTER(C.c_double)),
+        ("cost_batch", C.c_int32),
+        ("z_stride", C.c_int64),
+        ("align", C.c_int32),
+    ]
+
+
+class QlnDims(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("N", C.c_int32),
+        ("n_nlp", C.c_int32),
+        ("m_nlp_max", C.c_int32),
+        ("nnz_max", C.c_int32),
+        ("nnz_dynamic", C.c_int32),
+        ("z_stride", C.c_int64),
+        ("z_total", C.c_int64),
+        ("c_total", C.c_int64),
+        ("j_total", C.c_int64),
+    ]
+
+
+class QlnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"qln error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/qln_evaluator.h declares
+_vp, _dp = C.c_void_p, C.c_void_p  # device or host double* passed as raw addresses
+_i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+SIGNATURES = {
+    "qln_last_error": (C.c_char_p, []),
+    "qln_version": (C.c_char_p, []),
+    "qln_create": (C.c_int, [C.POINTER(QlnBatchDesc), C.c_int, C.POINTER(_vp)]),
+    "qln_destroy": (C.c_int, [_vp]),
+    "qln_set_stream": (C.c_int, [_vp, _vp]),
+    "qln_synchronize": (C.c_int, [_vp]),
+    "qln_get_dims": (C.c_int, [_vp, C.POINTER(QlnDims)]),
+    "qln_get_offsets": (C.c_int, [_vp, _i64p, _i64p]),
+    "qln_problem_dims": (C.c_int, [_vp, C.c_int32, _i32p, _i32p]),
+    "qln_constraint_index_ranges": (C.c_int, [_vp, C.c_int32, _i32p]),
+    "qln_constraint_bounds": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    "qln_jacobian_structure": (C.c_int, [_vp, C.c_int32, _i32p, _i32p]),
+    "qln_eval_objective": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_objective_gradient": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_constraint": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_constraint_jacobian": (C.c_int, [_vp, _dp, _dp, C.c_uint32]),
+    "qln_eval_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32]),
+    "qln_jacobian_init_constants": (C.c_int, [_vp, _dp]),
+    "qln_eval_objective_host": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_objective_gradient_host": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_constraint_host": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_constraint_jacobian_host": (C.c_int, [_vp, _dp, _dp]),
+    "qln_eval_constraint_jacobian_dense_host": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    "qln_time_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libqln_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C quadruped_landing_amd/csrc` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != QLN_OK:
+        raise QlnError(rc, lib().qln_last_error().decode())

@@ -1,0 +1,483 @@
+// qln_api.cpp -- the C ABI of include/qln_evaluator.h on top of the gfx950 kernels.
+//
+// Owns: the handle (device copies of the problem descriptors, offset tables, lazily allocated
+// staging for the host-pointer MOI mode).  Never owns or reallocates caller buffers, never throws
+// across the boundary, never calls exit (SURVEY.md 8b "Errors"/"Ownership").
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/qln_evaluator.h"
+#include "qln_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define QLN_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(QLN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// sizes of src/nlp.jl:48-87
+int32_t m_nlp_of(int32_t N, int32_t kt) { return 18 * N - kt + 16; }
+int32_t nnz_dyn_of(int32_t N) { return 300 * (N - 1) + N; }
+int32_t nnz_of(int32_t N, int32_t kt) { return nnz_dyn_of(N) + 435 + 15 * (N - 1) + 3 * N - kt + 3; }
+
+void cinds_of(int32_t N, int32_t kt, int32_t out[14]) {
+    int32_t e = 0;
+    const int32_t len[7] = {15, 14, 15 * (N - 1), N, N - kt + 1, 1, N};
+    for (int i = 0; i < 7; ++i) {
+        out[2 * i] = e + 1;
+        e += len[i];
+        out[2 * i + 1] = e;
+    }
+}
+
+}  // namespace
+
+struct qln_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    qln::BatchParams p{};
+    qln_dims dims{};
+    std::vector<int32_t> k_trans, init_mode;
+    std::vector<int64_t> c_off, j_off;
+    // device storage owned by the handle
+    int32_t* d_k_trans = nullptr;
+    int32_t* d_init_mode = nullptr;
+    double* d_x0 = nullptr;
+    double* d_xf = nullptr;
+    double* d_cost = nullptr;
+    int64_t* d_c_off = nullptr;
+    int64_t* d_j_off = nullptr;
+    // staging for host-pointer mode
+    double* s_Z = nullptr;
+    double* s_c = nullptr;
+    double* s_vals = nullptr;
+    double* s_f = nullptr;
+    double* s_grad = nullptr;
+    std::vector<double> h_vals_one;
+};
+
+namespace {
+
+template <class T>
+int upload(T** dst, const T* src, size_t n) {
+    QLN_HIP(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) QLN_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return QLN_OK;
+}
+
+int ensure(double** buf, int64_t n) {
+    if (*buf) return QLN_OK;
+    QLN_HIP(hipMalloc(reinterpret_cast<void**>(buf), std::max<int64_t>(n, 1) * sizeof(double)));
+    return QLN_OK;
+}
+
+int check_handle(const qln_handle* h) {
+    if (!h) return fail(QLN_ERR_INVALID_ARGUMENT, "null handle");
+    return QLN_OK;
+}
+
+int bind_device(const qln_handle* h) {
+    QLN_HIP(hipSetDevice(h->device));
+    return QLN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qln_last_error(void) { return g_err.c_str(); }
+const char* qln_version(void) { return "quadruped_landing_amd 0.1 (gfx950)"; }
+
+int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
+    if (!d || !out) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: null argument");
+    *out = nullptr;
+    if (d->B < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: B must be >= 1");
+    if (d->N < 2) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N must be >= 2");
+    if (d->N > 50000000 / 20) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N too large for 32-bit indices");
+    if (!d->k_trans || !d->init_mode || !d->x0 || !d->xf || !d->cost)
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: null descriptor array");
+    if (d->cost_batch != 1 && d->cost_batch != d->B)
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: cost_batch must be 1 or B");
+    const int32_t n_nlp = 20 * d->N - 5;
+    const int64_t z_stride = d->z_stride ? d->z_stride : n_nlp;
+    if (z_stride < n_nlp) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: z_stride < n_nlp");
+    int64_t align = d->align ? d->align : 16;
+    if (align < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: align must be >= 1");
+    for (int32_t b = 0; b < d->B; ++b) {
+        if (d->k_trans[b] < 1 || d->k_trans[b] > d->N + 1)
+            return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: k_trans out of range [1, N+1] at problem " + std::to_string(b));
+        if (d->init_mode[b] != 1 && d->init_mode[b] != 2)
+            return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: init_mode must be 1 or 2 at problem " + std::to_string(b));
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(QLN_ERR_NO_DEVICE, "qln_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: bad device ordinal");
+
+    qln_handle* h = new (std::nothrow) qln_handle();
+    if (!h) return fail(QLN_ERR_HIP, "qln_create: out of host memory");
+    h->device = device;
+    h->k_trans.assign(d->k_trans, d->k_trans + d->B);
+    h->init_mode.assign(d->init_mode, d->init_mode + d->B);
+    h->c_off.resize(d->B);
+    h->j_off.resize(d->B);
+    const int64_t jalign = (align % 2) ? align * 2 : align;  // keep j_off even: 16-byte stores
+    int64_t co = 0, jo = 0;
+    int32_t m_max = 0, nnz_max = 0;
+    for (int32_t b = 0; b < d->B; ++b) {
+        const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b]);
+        h->c_off[b] = co;
+        h->j_off[b] = jo;
+        co = round_up(co + m, align);
+        jo = round_up(jo + nz, jalign);
+        m_max = std::max(m_max, m);
+        nnz_max = std::max(nnz_max, nz);
+    }
+    qln_dims& D = h->dims;
+    D.B = d->B;
+    D.N = d->N;
+    D.n_nlp = n_nlp;
+    D.m_nlp_max = m_max;
+    D.nnz_max = nnz_max;
+    D.nnz_dynamic = nnz_dyn_of(d->N);
+    D.z_stride = z_stride;
+    D.z_total = z_stride * (int64_t)d->B;
+    D.c_total = co;
+    D.j_total = jo;
+
+    int rc = QLN_OK;
+    auto bail = [&](int code) {
+        qln_destroy(h);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(QLN_ERR_HIP, "hipSetDevice failed"));
+    if ((rc = upload(&h->d_k_trans, d->k_trans, (size_t)d->B))) return bail(rc);
+    if ((rc = upload(&h->d_init_mode, d->init_mode, (size_t)d->B))) return bail(rc);
+    if ((rc = upload(&h->d_x0, d->x0, (size_t)d->B * 15))) return bail(rc);
+    if ((rc = upload(&h->d_xf, d->xf, (size_t)d->B * 15))) return bail(rc);
+    if ((rc = upload(&h->d_cost, d->cost, (size_t)d->cost_batch * d->N * QLN_COST_STRIDE))) return bail(rc);
+    if ((rc = upload(&h->d_c_off, h->c_off.data(), (size_t)d->B))) return bail(rc);
+    if ((rc = upload(&h->d_j_off, h->j_off.data(), (size_t)d->B))) return bail(rc);
+
+    qln::BatchParams& P = h->p;
+    P.B = d->B;
+    P.N = d->N;
+    P.g = d->model.g;
+    P.mb = d->model.mb;
+    P.mf = d->model.mf;
+    P.lb = d->model.lb;
+    P.k_trans = h->d_k_trans;
+    P.init_mode = h->d_init_mode;
+    P.x0 = h->d_x0;
+    P.xf = h->d_xf;
+    P.cost = h->d_cost;
+    P.cost_batch = d->cost_batch;
+    P.z_stride = z_stride;
+    P.c_off = h->d_c_off;
+    P.j_off = h->d_j_off;
+    *out = h;
+    return QLN_OK;
+}
+
+int qln_destroy(qln_handle* h) {
+    if (!h) return QLN_OK;
+    (void)hipSetDevice(h->device);
+    void* bufs[] = {h->d_k_trans, h->d_init_mode, h->d_x0, h->d_xf, h->d_cost, h->d_c_off, h->d_j_off,
+                    h->s_Z,       h->s_c,         h->s_vals, h->s_f, h->s_grad};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete h;
+    return QLN_OK;
+}
+
+int qln_set_stream(qln_handle* h, void* hip_stream) {
+    if (int rc = check_handle(h)) return rc;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return QLN_OK;
+}
+
+int qln_synchronize(qln_handle* h) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    return QLN_OK;
+}
+
+int qln_get_dims(const qln_handle* h, qln_dims* out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_get_dims: null out");
+    *out = h->dims;
+    return QLN_OK;
+}
+
+int qln_get_offsets(const qln_handle* h, int64_t* c_off, int64_t* j_off) {
+    if (int rc = check_handle(h)) return rc;
+    if (c_off) std::copy(h->c_off.begin(), h->c_off.end(), c_off);
+    if (j_off) std::copy(h->j_off.begin(), h->j_off.end(), j_off);
+    return QLN_OK;
+}
+
+static int check_problem(const qln_handle* h, int32_t b) {
+    if (int rc = check_handle(h)) return rc;
+    if (b < 0 || b >= h->dims.B) return fail(QLN_ERR_INVALID_ARGUMENT, "problem index out of range");
+    return QLN_OK;
+}
+
+int qln_problem_dims(const qln_handle* h, int32_t b, int32_t* m_nlp, int32_t* nnz) {
+    if (int rc = check_problem(h, b)) return rc;
+    if (m_nlp) *m_nlp = m_nlp_of(h->dims.N, h->k_trans[b]);
+    if (nnz) *nnz = nnz_of(h->dims.N, h->k_trans[b]);
+    return QLN_OK;
+}
+
+int qln_constraint_index_ranges(const qln_handle* h, int32_t b, int32_t cinds[14]) {
+    if (int rc = check_problem(h, b)) return rc;
+    if (!cinds) return fail(QLN_ERR_INVALID_ARGUMENT, "null cinds");
+    cinds_of(h->dims.N, h->k_trans[b], cinds);
+    return QLN_OK;
+}
+
+int qln_constraint_bounds(const qln_handle* h, int32_t b, double* lb, double* ub) {
+    // src/nlp.jl:66-69: lb = ub = 0 except ub[c_body_pos_inds] = Inf
+    if (int rc = check_problem(h, b)) return rc;
+    if (!lb || !ub) return fail(QLN_ERR_INVALID_ARGUMENT, "null bounds");
+    int32_t ci[14];
+    cinds_of(h->dims.N, h->k_trans[b], ci);
+    for (int32_t i = 0; i < ci[13]; ++i) {
+        lb[i] = 0.0;
+        ub[i] = 0.0;
+    }
+    for (int32_t i = ci[12]; i <= ci[13]; ++i) ub[i - 1] = std::numeric_limits<double>::infinity();
+    return QLN_OK;
+}
+
+int qln_jacobian_structure(const qln_handle* h, int32_t b, int32_t* rows, int32_t* cols) {
+    if (int rc = check_problem(h, b)) return rc;
+    if (!rows || !cols) return fail(QLN_ERR_INVALID_ARGUMENT, "null rows/cols");
+    const int32_t N = h->dims.N, kt = h->k_trans[b], im = h->init_mode[b];
+    int32_t ci[14];
+    cinds_of(N, kt, ci);
+    const int32_t r_init = ci[0] - 1, r_term = ci[2] - 1, r_dyn = ci[4] - 1, r_ci = ci[6] - 1, r_co = ci[8] - 1,
+                  r_fc = ci[10] - 1, r_bp = ci[12] - 1;
+    const int32_t y_init = (im == 1) ? 4 : 6, y_other = (im == 1) ? 6 : 4;
+    int64_t e = 0;
+    auto put = [&](int32_t r, int32_t c) {
+        rows[e] = r;
+        cols[e] = c;
+        ++e;
+    };
+    for (int32_t k = 0; k < N - 1; ++k)  // D[ci, [xi[k]; ui[k]]], src/constraints.jl:186-198
+        for (int32_t c = 0; c < 20; ++c)
+            for (int32_t r = 0; r < 15; ++r) put(r_dyn + 15 * k + r, 20 * k + c);
+    for (int32_t k = 0; k < N; ++k) put(r_bp + k, 20 * k + 2);       // :269-273
+    for (int32_t c = 0; c < 15; ++c)                                  // :228
+        for (int32_t r = 0; r < 15; ++r) put(r_init + r, c);
+    for (int32_t c = 0; c < 15; ++c)                                  // :229
+        for (int32_t r = 0; r < 14; ++r) put(r_term + r, 20 * (N - 1) + c);
+    for (int32_t k = 0; k < N - 1; ++k)                               // :200 (diagonal of -I(n))
+        for (int32_t r = 0; r < 15; ++r) put(r_dyn + 15 * k + r, 20 * (k + 1) + r);
+    for (int32_t k = 0; k < N; ++k) put(r_ci + k, 20 * k + y_init);   // :235-243
+    for (int32_t K = kt; K <= N; ++K) put(r_co + (K - kt), 20 * (K - 1) + y_other);  // :246-256
+    put(r_fc, 20 * (N - 2) + 16);                                     // :259
+    put(r_fc, 20 * (N - 2) + 18);                                     // :260
+    for (int32_t k = 0; k < N; ++k) put(r_bp + k, 20 * k + 1);        // :266
+    return QLN_OK;
+}
+
+// ------------------------------------------------------------------ device-pointer mode
+
+int qln_eval_objective(qln_handle* h, const double* Z, double* f) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !f) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_objective(h->p, Z, f, h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_objective_gradient(qln_handle* h, const double* Z, double* grad) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !grad) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_gradient: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_objective_gradient(h->p, Z, grad, h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint(qln_handle* h, const double* Z, double* c) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, nullptr, 0, h->stream));
+    return QLN_OK;
+}
+
+static int check_vals(const double* vals) {
+    if (!vals) return fail(QLN_ERR_INVALID_ARGUMENT, "null vals");
+    if (reinterpret_cast<uintptr_t>(vals) % 16) return fail(QLN_ERR_INVALID_ARGUMENT, "vals must be 16-byte aligned");
+    return QLN_OK;
+}
+
+int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, uint32_t flags) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian: null Z");
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, nullptr, vals, flags, h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_and_jacobian: null pointer");
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream));
+    return QLN_OK;
+}
+
+int qln_jacobian_init_constants(qln_handle* h, double* vals) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_jacobian_constants(h->p, vals, h->stream));
+    return QLN_OK;
+}
+
+// ------------------------------------------------------------------ host-pointer (MOI) mode
+
+int qln_eval_objective_host(qln_handle* h, const double* Z, double* f) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !f) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_host: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    if (int rc = ensure(&h->s_f, h->dims.B)) return rc;
+    QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QLN_HIP(qln::launch_objective(h->p, h->s_Z, h->s_f, h->stream));
+    QLN_HIP(hipMemcpyAsync(f, h->s_f, h->dims.B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_objective_gradient_host(qln_handle* h, const double* Z, double* grad) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !grad) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_gradient_host: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    if (int rc = ensure(&h->s_grad, h->dims.z_total)) return rc;
+    QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QLN_HIP(hipMemsetAsync(h->s_grad, 0, h->dims.z_total * sizeof(double), h->stream));
+    QLN_HIP(qln::launch_objective_gradient(h->p, h->s_Z, h->s_grad, h->stream));
+    QLN_HIP(hipMemcpyAsync(grad, h->s_grad, h->dims.z_total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint_host(qln_handle* h, const double* Z, double* c) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_host: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    if (int rc = ensure(&h->s_c, h->dims.c_total)) return rc;
+    QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->s_Z, h->s_c, nullptr, 0, h->stream));
+    QLN_HIP(hipMemcpyAsync(c, h->s_c, h->dims.c_total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* vals) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian_host: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
+    QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->s_Z, nullptr, h->s_vals, QLN_JAC_WRITE_CONSTANTS,
+                                            h->stream));
+    QLN_HIP(hipMemcpyAsync(vals, h->s_vals, h->dims.j_total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const double* Z, double* jac) {
+    // MOI.eval_constraint_jacobian with use_sparse_jacobian=false (src/moi.jl:15-24): the values are
+    // computed on the GPU; the host only scatters them into the caller's column-major matrix,
+    // touching exactly the write-set of jac_c! (src/constraints.jl:219-274).
+    if (int rc = check_problem(h, b)) return rc;
+    if (!Z || !jac) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian_dense_host: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
+    const int32_t N = h->dims.N, kt = h->k_trans[b];
+    const int32_t nnz = nnz_of(N, kt);
+    const int64_t m = m_nlp_of(N, kt);
+    h->h_vals_one.resize(nnz);
+    QLN_HIP(hipMemcpyAsync(h->s_Z + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->s_Z, nullptr, h->s_vals, QLN_JAC_WRITE_CONSTANTS, h->stream));
+    QLN_HIP(hipMemcpyAsync(h->h_vals_one.data(), h->s_vals + h->j_off[b], nnz * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int32_t> rows(nnz), cols(nnz);
+    if (int rc = qln_jacobian_structure(h, b, rows.data(), cols.data())) return rc;
+    // D[ci, xi[k+1]] .= -I(n) assigns the whole 15x15 block (explicit zeros off the diagonal)
+    int32_t ci[14];
+    cinds_of(N, kt, ci);
+    for (int32_t k = 0; k < N - 1; ++k)
+        for (int32_t c = 0; c < 15; ++c)
+            for (int32_t r = 0; r < 15; ++r)
+                if (r != c) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * (k + 1) + c)] = 0.0;
+    const double* v = h->h_vals_one.data();
+    for (int32_t e = 0; e < nnz; ++e) jac[rows[e] + m * (int64_t)cols[e]] = v[e];
+    return QLN_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+
+int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags, int32_t warmup,
+                                     int32_t iters, float* ms_each) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c || !ms_each || iters < 1 || warmup < 0)
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_time_constraint_and_jacobian: bad argument");
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (auto& e : ev) QLN_HIP(hipEventCreate(&e));
+    int rc = QLN_OK;
+    for (int32_t i = 0; i < warmup && rc == QLN_OK; ++i)
+        if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "warmup launch failed");
+    for (int32_t i = 0; i < iters && rc == QLN_OK; ++i) {
+        (void)hipEventRecord(ev[2 * i], h->stream);
+        if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "timed launch failed");
+        (void)hipEventRecord(ev[2 * i + 1], h->stream);
+    }
+    if (rc == QLN_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(QLN_ERR_HIP, "stream synchronize failed");
+    for (int32_t i = 0; i < iters && rc == QLN_OK; ++i)
+        if (hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// qln_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched landing-NLP evaluator.
+//
+// Hot path: k_constraint_jacobian -- eval_c! (src/constraints.jl:145-158) and jac_c!
+// (src/constraints.jl:212-291) of every knot of every problem in one launch.
+//
+// Mapping.  One 64-lane wavefront (= one workgroup) per landing problem; lane l owns dynamics knot
+// kc0 + l.  The problem's slice of the decision vector is read with coalesced loads into LDS, each
+// lane picks its (x_k, u_k, x_{k+1}) out of LDS, integrates the RK4 step in registers (literal
+// reference operation order, no FMA contraction, so the residual rounds like the reference) and
+// forms the 85 structurally non-zero entries of the 15x20 step Jacobian in closed form.  The dense
+// 300-double blocks the reference's Jacobian is made of are then assembled T knots at a time in an
+// LDS tile whose structural zeros are written once, and streamed to HBM as full 16-byte-per-lane,
+// 1-KiB-per-instruction stores.  The kernel is HBM-write bound (2400 B of Jacobian per knot against
+// ~0.4 kflop), so everything is organised around that store stream.
+//
+// Closed form of the step (DESIGN.md "Step Jacobian"): with zero-order-hold forces every
+// acceleration except the body's angular one is constant over the step, so RK4 reproduces
+//   p+ = p + h v + h^2/2 a,  v+ = v + h a            (body, and the free foot; pinned foot: identity)
+//   w+ = w  + (h tau0 + h^2/2 tauv + h^3/6 taua)/Ib
+//   th+ = th + h w + (h^2/2 tau0 + h^3/6 tauv + h^4/24 taua)/Ib
+// where tau0/tauv/taua are the force moment evaluated on relative positions / velocities /
+// accelerations.  Differentiating these gives every entry of ForwardDiff.jacobian of the RK4 step
+// (src/planar_quadruped.jl:225-248) up to rounding.
+#include "qln_device.h"
+
+namespace qln {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlk = 300;  // 15 x 20 doubles per step block
+
+// ---------------------------------------------------------------------------------------------
+// Value path: literal restatement of contact{1,2,3}_dynamics (src/planar_quadruped.jl:36-185).
+// f1free/f2free select the mode: mode 1 = foot 2 free, mode 2 = foot 1 free, mode 3 = none.
+// ---------------------------------------------------------------------------------------------
+struct StepConst {
+    double abx, aby;    // body acceleration
+    double a1x, a1y;    // foot 1 acceleration (0 if pinned)
+    double a2x, a2y;    // foot 2 acceleration (0 if pinned)
+};
+
+__device__ __forceinline__ void dynamics(const double (&s)[14], const double (&u)[5], const StepConst& k, bool f1free,
+                                         bool f2free, double Ib, double (&f)[14]) {
+    const double F1x = u[0], F1y = u[1], F2x = u[2], F2y = u[3];
+    // tauF = -F1x*(p1[2]-pb[2]) + F1y*(p1[1]-pb[1]) - F2x*(p2[2]-pb[2]) + F2y*(p2[1]-pb[1])
+    const double tauF = -F1x * (s[4] - s[1]) + F1y * (s[3] - s[0]) - F2x * (s[6] - s[1]) + F2y * (s[5] - s[0]);
+    f[0] = s[7];
+    f[1] = s[8];
+    f[2] = s[9];
+    f[3] = f1free ? s[10] : 0.0;
+    f[4] = f1free ? s[11] : 0.0;
+    f[5] = f2free ? s[12] : 0.0;
+    f[6] = f2free ? s[13] : 0.0;
+    f[7] = k.abx;
+    f[8] = k.aby;
+    f[9] = tauF / Ib;
+    f[10] = k.a1x;
+    f[11] = k.a1y;
+    f[12] = k.a2x;
+    f[13] = k.a2y;
+}
+
+// contact*_dynamics_rk4 (src/planar_quadruped.jl:189-221)
+__device__ __forceinline__ void rk4_step(const double (&x)[15], const double (&u)[5], const StepConst& k, bool f1free,
+                                         bool f2free, double Ib, double (&xn)[15]) {
+    const double h = u[4];
+    const double hh = 0.5 * h;
+    double s0[14], s[14], f1[14], f2[14], f3[14], f4[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s0[i] = x[i];
+    dynamics(s0, u, k, f1free, f2free, Ib, f1);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s[i] = s0[i] + hh * f1[i];
+    dynamics(s, u, k, f1free, f2free, Ib, f2);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s[i] = s0[i] + hh * f2[i];
+    dynamics(s, u, k, f1free, f2free, Ib, f3);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s[i] = s0[i] + h * f3[i];
+    dynamics(s, u, k, f1free, f2free, Ib, f4);
+    const double h6 = h / 6.0;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) xn[i] = s0[i] + h6 * (((f1[i] + 2 * f2[i]) + 2 * f3[i]) + f4[i]);
+    xn[14] = x[14] + u[4];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused constraint + Jacobian kernel.
+// ---------------------------------------------------------------------------------------------
+template <int T, bool WITH_C, bool WITH_J>
+__global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P, int32_t b_begin, const double* __restrict__ Z,
+                                                              double* __restrict__ C, double* __restrict__ V,
+                                                              uint32_t flags) {
+    static_assert(T * kBlk >= kWave * 20 + 15, "Z slice of one 64-knot chunk must fit in the Jacobian tile it aliases");
+    __shared__ double2 s_j2[T * kBlk / 2];  // T dense step blocks; aliased by the staged Z slice
+    __shared__ double s_c[T * 15];
+    double* const s_j = reinterpret_cast<double*>(s_j2);
+    double* const s_z = s_j;
+
+    const int lane = threadIdx.x;
+    const int b = b_begin + blockIdx.x;
+    const int N = P.N;
+    const int kt = P.k_trans[b];
+    const int im = P.init_mode[b];
+    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+    double* __restrict__ Cb = WITH_C ? C + P.c_off[b] : nullptr;
+    double* __restrict__ Vb = WITH_J ? V + P.j_off[b] : nullptr;
+
+    const double g = P.g, mb = P.mb, mf = P.mf, lb = P.lb;
+    const double Ib = mb * (lb * lb) / 12;  // mb * lb^2 / 12, src/planar_quadruped.jl:41
+
+    // offsets of the constraint groups inside c (0-based; cinds of src/nlp.jl:48-63)
+    const int o_dyn = 29;
+    const int o_ci = o_dyn + 15 * (N - 1);
+    const int o_co = o_ci + N;
+    const int o_fc = o_co + (N - kt + 1);
+    const int o_bp = o_fc + 1;
+    const int a_init = (im == 1) ? 4 : 6;  // y of the initially touching foot
+    const int a_other = (im == 1) ? 6 : 4;
+
+    if (WITH_C) {
+        // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
+        // c6 = F1y + F2y + mb*g of u_{N-1} (:154)
+        if (lane < 15) {
+            Cb[lane] = Zb[lane] - P.x0[(int64_t)b * 15 + lane];
+        } else if (lane < 29) {
+            const int i = lane - 15;
+            Cb[lane] = Zb[20 * (N - 1) + i] - P.xf[(int64_t)b * 15 + i];
+        } else if (lane == 29) {
+            const double* ul = Zb + 20 * (N - 2) + 15;
+            Cb[o_fc] = ul[1] + ul[3] + mb * g;
+        }
+    }
+    if (WITH_J && (flags & 1u)) {
+        // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
+        double* Vc = Vb + kBlk * (N - 1) + N;
+        const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
+        for (int i = lane; i < n_const; i += kWave) {
+            double v;
+            if (i < 225) {
+                v = (i % 15 == i / 15) ? 1.0 : 0.0;
+            } else if (i < 435) {
+                const int j = i - 225;
+                v = (j % 14 == j / 14) ? 1.0 : 0.0;
+            } else if (i < 435 + 15 * (N - 1)) {
+                v = -1.0;
+            } else {
+                v = 1.0;
+            }
+            Vc[i] = v;
+        }
+    }
+
+    for (int kc0 = 0; kc0 < N - 1; kc0 += kWave) {
+        const int nk = min(kWave, N - 1 - kc0);
+        const int nz = 20 * nk + 15;
+        __syncthreads();  // previous chunk's drain has finished reading the tile
+        for (int i = lane; i < nz; i += kWave) s_z[i] = Zb[20 * kc0 + i];
+        __syncthreads();
+
+        const bool valid = lane < nk;
+        const int k = kc0 + lane;  // 0-based dynamics knot; K = k + 1 in the reference's numbering
+        double x[15], u[5], xnext[15];
+        {
+            const double* zl = s_z + 20 * (valid ? lane : 0);
+#pragma unroll
+            for (int i = 0; i < 15; ++i) x[i] = zl[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) u[i] = zl[15 + i];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) xnext[i] = zl[20 + i];
+        }
+        __syncthreads();
+        if (WITH_J) {
+            // structural zeros of the tile: written here, never touched by the value writes below
+            const double2 zero2 = make_double2(0.0, 0.0);
+            for (int i = lane; i < T * kBlk / 2; i += kWave) s_j2[i] = zero2;
+        }
+
+        // mode schedule, src/constraints.jl:23-37: K < k_trans-1 -> init mode; K == k_trans-1 ->
+        // init mode then jump map; else mode 3
+        const int K = k + 1;
+        const int mode = (K <= kt - 1) ? im : 3;
+        const bool jump = (K == kt - 1);
+        const bool f1free = (mode == 2);
+        const bool f2free = (mode == 1);
+
+        const double F1x = u[0], F1y = u[1], F2x = u[2], F2y = u[3], h = u[4];
+        StepConst sc;
+        sc.abx = (F1x + F2x) / mb;
+        sc.aby = (F1y + F2y) / mb + g;
+        sc.a1x = f1free ? (-F1x / mf) : 0.0;
+        sc.a1y = f1free ? (-F1y / mf + g) : 0.0;
+        sc.a2x = f2free ? (-F2x / mf) : 0.0;
+        sc.a2y = f2free ? (-F2y / mf + g) : 0.0;
+
+        double cd[15];
+        if (WITH_C) {
+            double xn[15];
+            rk4_step(x, u, sc, f1free, f2free, Ib, xn);
+            if (jump) {  // jump1_map / jump2_map, src/planar_quadruped.jl:250-260
+                xn[4] = 0.0;
+                xn[6] = 0.0;
+                xn[10] = xn[11] = xn[12] = xn[13] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) cd[i] = xn[i] - xnext[i];
+
+            // per-knot scalar rows: contact (src/constraints.jl:48-91) and clearance (:98-113)
+            if (valid) {
+                Cb[o_ci + k] = x[a_init == 4 ? 4 : 6];
+                if (K >= kt) Cb[o_co + (K - kt)] = x[a_other == 4 ? 4 : 6];
+                Cb[o_bp + k] = x[1] - lb / 2 * fabs(sin(x[2]));
+                if (k == N - 2) {  // this lane also holds the terminal knot x_N
+                    Cb[o_ci + k + 1] = xnext[a_init == 4 ? 4 : 6];
+                    if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = xnext[a_other == 4 ? 4 : 6];
+                    Cb[o_bp + k + 1] = xnext[1] - lb / 2 * fabs(sin(xnext[2]));
+                }
+            }
+        }
+
+        // ---- the 85 non-zeros of the step block, closed form (see header) ---------------------
+        double jv[85];
+        if (WITH_J) {
+            // clearance d/dtheta (src/constraints.jl:269-273; theta == 0 takes the + branch)
+            if (valid) {
+                double* Vt = Vb + kBlk * (N - 1);
+                Vt[k] = (x[2] > 0) ? (-lb / 2 * cos(x[2])) : (lb / 2 * cos(x[2]));
+                if (k == N - 2) Vt[k + 1] = (xnext[2] > 0) ? (-lb / 2 * cos(xnext[2])) : (lb / 2 * cos(xnext[2]));
+            }
+            const double m1 = f1free ? 1.0 : 0.0, m2 = f2free ? 1.0 : 0.0;
+            const double keep = jump ? 0.0 : 1.0;  // jump*_jacobian() rows 5,7,11..15 (slot 15 too: quirk Q1)
+            const double h2 = h * h, h3 = h2 * h, h4 = h2 * h2;
+            const double iIb = 1.0 / Ib;
+            const double Aw = h * iIb;                // omega row: weight of tau0
+            const double At = 0.5 * h2 * iIb;         // theta row: tau0;  omega row: tauv
+            const double Bt = h3 * iIb * (1.0 / 6.0); // theta row: tauv;  omega row: taua
+            const double Ct = h4 * iIb * (1.0 / 24.0);
+            const double sFx = F1x + F2x, sFy = F1y + F2y;
+            const double r1x = x[3] - x[0], r1y = x[4] - x[1], r2x = x[5] - x[0], r2y = x[6] - x[1];
+            const double w1x = m1 * x[10] - x[7], w1y = m1 * x[11] - x[8];
+            const double w2x = m2 * x[12] - x[7], w2y = m2 * x[13] - x[8];
+            const double tau0 = r1x * F1y - r1y * F1x + r2x * F2y - r2y * F2x;
+            const double tauv = w1x * F1y - w1y * F1x + w2x * F2y - w2y * F2x;
+            const double ga1 = g * (1.0 - m1), ga2 = g * (1.0 - m2);
+            const double taua = ga1 * F1x + ga2 * F2x;
+            const double hmb = h / mb, h2mb = 0.5 * h2 / mb;
+            const double hmf = h / mf, h2mf = 0.5 * h2 / mf;
+            int n = 0;
+            // row 0 (xb): cols 0,7,15,17,19
+            jv[n++] = 1.0;
+            jv[n++] = h;
+            jv[n++] = h2mb;
+            jv[n++] = h2mb;
+            jv[n++] = x[7] + h * sc.abx;
+            // row 1 (yb): cols 1,8,16,18,19
+            jv[n++] = 1.0;
+            jv[n++] = h;
+            jv[n++] = h2mb;
+            jv[n++] = h2mb;
+            jv[n++] = x[8] + h * sc.aby;
+            // row 2 (theta): cols 0..13, 15..19
+            jv[n++] = -At * sFy;
+            jv[n++] = At * sFx;
+            jv[n++] = 1.0;
+            jv[n++] = At * F1y;
+            jv[n++] = -At * F1x;
+            jv[n++] = At * F2y;
+            jv[n++] = -At * F2x;
+            jv[n++] = -Bt * sFy;
+            jv[n++] = Bt * sFx;
+            jv[n++] = h;
+            jv[n++] = Bt * m1 * F1y;
+            jv[n++] = -Bt * m1 * F1x;
+            jv[n++] = Bt * m2 * F2y;
+            jv[n++] = -Bt * m2 * F2x;
+            jv[n++] = -At * r1y - Bt * w1y + Ct * ga1;
+            jv[n++] = At * r1x + Bt * w1x;
+            jv[n++] = -At * r2y - Bt * w2y + Ct * ga2;
+            jv[n++] = At * r2x + Bt * w2x;
+            jv[n++] = x[9] + (Aw * tau0 + At * tauv + Bt * taua);
+            // row 3 (x1): cols 3,10,15,19      row 4 (y1): cols 4,11,16,19 (masked at the jump)
+            jv[n++] = 1.0;
+            jv[n++] = m1 * h;
+            jv[n++] = -m1 * h2mf;
+            jv[n++] = m1 * (x[10] + h * sc.a1x);
+            jv[n++] = keep;
+            jv[n++] = keep * m1 * h;
+            jv[n++] = -keep * m1 * h2mf;
+            jv[n++] = keep * m1 * (x[11] + h * sc.a1y);
+            // row 5 (x2): cols 5,12,17,19      row 6 (y2): cols 6,13,18,19 (masked)
+            jv[n++] = 1.0;
+            jv[n++] = m2 * h;
+            jv[n++] = -m2 * h2mf;
+            jv[n++] = m2 * (x[12] + h * sc.a2x);
+            jv[n++] = keep;
+            jv[n++] = keep * m2 * h;
+            jv[n++] = -keep * m2 * h2mf;
+            jv[n++] = keep * m2 * (x[13] + h * sc.a2y);
+            // row 7 (vbx): cols 7,15,17,19     row 8 (vby): cols 8,16,18,19
+            jv[n++] = 1.0;
+            jv[n++] = hmb;
+            jv[n++] = hmb;
+            jv[n++] = sc.abx;
+            jv[n++] = 1.0;
+            jv[n++] = hmb;
+            jv[n++] = hmb;
+            jv[n++] = sc.aby;
+            // row 9 (omega): cols 0,1,3..13,15..19
+            jv[n++] = -Aw * sFy;
+            jv[n++] = Aw * sFx;
+            jv[n++] = Aw * F1y;
+            jv[n++] = -Aw * F1x;
+            jv[n++] = Aw * F2y;
+            jv[n++] = -Aw * F2x;
+            jv[n++] = -At * sFy;
+            jv[n++] = At * sFx;
+            jv[n++] = 1.0;
+            jv[n++] = At * m1 * F1y;
+            jv[n++] = -At * m1 * F1x;
+            jv[n++] = At * m2 * F2y;
+            jv[n++] = -At * m2 * F2x;
+            jv[n++] = -Aw * r1y - At * w1y + Bt * ga1;
+            jv[n++] = Aw * r1x + At * w1x;
+            jv[n++] = -Aw * r2y - At * w2y + Bt * ga2;
+            jv[n++] = Aw * r2x + At * w2x;
+            jv[n++] = iIb * (tau0 + h * tauv + 0.5 * h2 * taua);
+            // rows 10..13 (foot velocities; masked at the jump): diag, own force, h
+            jv[n++] = keep;
+            jv[n++] = -keep * m1 * hmf;
+            jv[n++] = keep * sc.a1x;
+            jv[n++] = keep;
+            jv[n++] = -keep * m1 * hmf;
+            jv[n++] = keep * sc.a1y;
+            jv[n++] = keep;
+            jv[n++] = -keep * m2 * hmf;
+            jv[n++] = keep * sc.a2x;
+            jv[n++] = keep;
+            jv[n++] = -keep * m2 * hmf;
+            jv[n++] = keep * sc.a2y;
+            // row 14 (clock; masked at the jump -- quirk Q1): cols 14,19
+            jv[n++] = keep;
+            jv[n++] = keep;
+        }
+
+        // ---- assemble T knots at a time in LDS and stream them out ----------------------------
+        const int nt = (nk + T - 1) / T;
+        for (int t = 0; t < nt; ++t) {
+            const int kb = kc0 + t * T;           // first knot of the sub-tile
+            const int nkt = min(T, nk - t * T);   // knots in it
+            if (valid && (lane / T) == t) {
+                const int r = lane - t * T;
+                if (WITH_C) {
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) s_c[r * 15 + i] = cd[i];
+                }
+                if (WITH_J) {
+                    double* jr = s_j + r * kBlk;
+#define JW(row, col, idx) jr[(row) + 15 * (col)] = jv[idx]
+                    JW(0, 0, 0); JW(0, 7, 1); JW(0, 15, 2); JW(0, 17, 3); JW(0, 19, 4);
+                    JW(1, 1, 5); JW(1, 8, 6); JW(1, 16, 7); JW(1, 18, 8); JW(1, 19, 9);
+                    JW(2, 0, 10); JW(2, 1, 11); JW(2, 2, 12); JW(2, 3, 13); JW(2, 4, 14); JW(2, 5, 15); JW(2, 6, 16);
+                    JW(2, 7, 17); JW(2, 8, 18); JW(2, 9, 19); JW(2, 10, 20); JW(2, 11, 21); JW(2, 12, 22); JW(2, 13, 23);
+                    JW(2, 15, 24); JW(2, 16, 25); JW(2, 17, 26); JW(2, 18, 27); JW(2, 19, 28);
+                    JW(3, 3, 29); JW(3, 10, 30); JW(3, 15, 31); JW(3, 19, 32);
+                    JW(4, 4, 33); JW(4, 11, 34); JW(4, 16, 35); JW(4, 19, 36);
+                    JW(5, 5, 37); JW(5, 12, 38); JW(5, 17, 39); JW(5, 19, 40);
+                    JW(6, 6, 41); JW(6, 13, 42); JW(6, 18, 43); JW(6, 19, 44);
+                    JW(7, 7, 45); JW(7, 15, 46); JW(7, 17, 47); JW(7, 19, 48);
+                    JW(8, 8, 49); JW(8, 16, 50); JW(8, 18, 51); JW(8, 19, 52);
+                    JW(9, 0, 53); JW(9, 1, 54); JW(9, 3, 55); JW(9, 4, 56); JW(9, 5, 57); JW(9, 6, 58); JW(9, 7, 59);
+                    JW(9, 8, 60); JW(9, 9, 61); JW(9, 10, 62); JW(9, 11, 63); JW(9, 12, 64); JW(9, 13, 65);
+                    JW(9, 15, 66); JW(9, 16, 67); JW(9, 17, 68); JW(9, 18, 69); JW(9, 19, 70);
+                    JW(10, 10, 71); JW(10, 15, 72); JW(10, 19, 73);
+                    JW(11, 11, 74); JW(11, 16, 75); JW(11, 19, 76);
+                    JW(12, 12, 77); JW(12, 17, 78); JW(12, 19, 79);
+                    JW(13, 13, 80); JW(13, 18, 81); JW(13, 19, 82);
+                    JW(14, 14, 83); JW(14, 19, 84);
+#undef JW
+                }
+            }
+            __syncthreads();
+            if (WITH_J) {
+                // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
+                double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
+                const int np = nkt * (kBlk / 2);
+#pragma unroll 4
+                for (int i = lane; i < np; i += kWave) dst[i] = s_j2[i];
+            }
+            if (WITH_C) {
+                double* __restrict__ dst = Cb + o_dyn + 15 * kb;
+                const int np = nkt * 15;
+                for (int i = lane; i < np; i += kWave) dst[i] = s_c[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// constants only (qln_jacobian_init_constants)
+__global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, double* __restrict__ V) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int N = P.N;
+    const int kt = P.k_trans[b];
+    double* Vc = V + P.j_off[b] + kBlk * (N - 1) + N;
+    const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
+    for (int i = lane; i < n_const; i += kWave) {
+        double v;
+        if (i < 225) {
+            v = (i % 15 == i / 15) ? 1.0 : 0.0;
+        } else if (i < 435) {
+            const int j = i - 225;
+            v = (j % 14 == j / 14) ? 1.0 : 0.0;
+        } else if (i < 435 + 15 * (N - 1)) {
+            v = -1.0;
+        } else {
+            v = 1.0;
+        }
+        Vc[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Objective (src/costs.jl:6-16) -- one wavefront per problem, lane per knot, and the reference's
+// sequential left-to-right sum over knots done by lane 0 so the value rounds like eval_f.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quad_form(const double* D, const double* v, int n) {
+    double s = (0.5 * (D[0] * v[0])) * v[0];
+    for (int i = 1; i < n; ++i) s = s + (0.5 * (D[i] * v[i])) * v[i];
+    return s;
+}
+__device__ __forceinline__ double dotn(const double* a, const double* v, int n) {
+    double s = a[0] * v[0];
+    for (int i = 1; i < n; ++i) s = s + a[i] * v[i];
+    return s;
+}
+
+__global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
+    __shared__ double s_term[kWave];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int N = P.N;
+    const double* Zb = Z + (int64_t)b * P.z_stride;
+    const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+    double J = 0.0;
+    for (int k0 = 0; k0 < N; k0 += kWave) {
+        const int k = k0 + lane;
+        double term = 0.0;
+        if (k < N) {
+            const double* ck = cost + (int64_t)k * 41;
+            double xv[15], uv[5];
+            for (int i = 0; i < 15; ++i) xv[i] = Zb[20 * k + i];
+            if (k < N - 1) {
+                for (int i = 0; i < 5; ++i) uv[i] = Zb[20 * k + 15 + i];
+                // stagecost, src/quadratic_cost.jl:44-47
+                const double l = (((quad_form(ck, xv, 15) + dotn(ck + 20, xv, 15)) + quad_form(ck + 15, uv, 5)) +
+                                  dotn(ck + 35, uv, 5)) + ck[40];
+                term = uv[4] * l;  // hk * stagecost
+            } else {
+                // termcost, src/quadratic_cost.jl:49-52
+                term = (quad_form(ck, xv, 15) + dotn(ck + 20, xv, 15)) + ck[40];
+            }
+        }
+        s_term[lane] = term;
+        __syncthreads();
+        if (lane == 0) {
+            const int n = min(kWave, N - k0);
+            for (int i = 0; i < n; ++i) J += s_term[i];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) F[b] = J;
+}
+
+// Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  One thread per entry.
+__global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const double* __restrict__ Z,
+                                                           double* __restrict__ G) {
+    const int N = P.N;
+    const int n_nlp = 20 * N - 5;
+    const int b = blockIdx.x;  // gridDim.x carries the batch (gridDim.y is limited to 65535)
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;
+    if (i >= n_nlp) return;
+    const double* Zb = Z + (int64_t)b * P.z_stride;
+    double* Gb = G + (int64_t)b * P.z_stride;
+    const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+    const int k = i / 20, j = i - 20 * k;
+    const double* ck = cost + (int64_t)k * 41;
+    const double z = Zb[i];
+    // Q*x + q for j < 15, R*u + r for the controls: table slots [0,20) and [20,40)
+    const double lin = ck[j] * z + ck[20 + j];
+    Gb[i] = (k < N - 1) ? Zb[20 * k + 19] * lin : lin;
+}
+
+template <int T>
+hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
+                       uint32_t flags, hipStream_t stream) {
+    dim3 grid(nb), block(kWave);
+    if (c && vals)
+        hipLaunchKernelGGL((k_constraint_jacobian<T, true, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+    else if (c)
+        hipLaunchKernelGGL((k_constraint_jacobian<T, true, false>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+    else
+        hipLaunchKernelGGL((k_constraint_jacobian<T, false, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
+                                      double* vals, uint32_t flags, hipStream_t stream) {
+    if (nb <= 0 || (!c && !vals)) return hipSuccess;
+    return launch_cj_t<8>(p, b_begin, nb, Z, c, vals, flags, stream);
+}
+
+hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream) {
+    hipLaunchKernelGGL(k_jacobian_constants, dim3(p.B), dim3(kWave), 0, stream, p, vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
+    hipLaunchKernelGGL(k_objective, dim3(p.B), dim3(kWave), 0, stream, p, Z, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
+    const int n_nlp = 20 * p.N - 5;
+    dim3 grid(p.B, (n_nlp + 255) / 256);
+    hipLaunchKernelGGL(k_objective_gradient, grid, dim3(256), 0, stream, p, Z, grad);
+    return hipGetLastError();
+}
+
+}  // namespace qln

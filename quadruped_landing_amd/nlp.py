@@ -1,0 +1,341 @@
+"""HybridNLP: the landing NLP (mirror of src/nlp.jl:13-114) generalised to a batch of B
+independent problems, evaluated by the gfx950 kernels through the C ABI.
+
+The index maps (xinds/uinds/cinds), bounds and sizes are host logic and are pure
+numpy; every evaluation (eval_f, grad_f, eval_c, jac_c) is a kernel launch behind
+include/qln_evaluator.h -- there is no CPU implementation of the arithmetic here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .planar_quadruped import PlanarQuadruped
+
+n, m = 15, 5
+
+
+# ----------------------------------------------------------------------------- index maps
+
+
+def num_primals(N: int) -> int:
+    """src/nlp.jl:86"""
+    return n * N + m * (N - 1)
+
+
+def num_duals(N: int, k_trans: int) -> int:
+    """src/nlp.jl:87 (= cinds[end][end])"""
+    return cinds(N, k_trans)[-1][-1]
+
+
+def xinds(N: int):
+    """src/nlp.jl:38, 1-based like the reference."""
+    return [np.arange(1, n + 1) + (k - 1) * (n + m) for k in range(1, N + 1)]
+
+
+def uinds(N: int):
+    """src/nlp.jl:39, 1-based."""
+    return [np.arange(n + 1, n + m + 1) + (k - 1) * (n + m) for k in range(1, N)]
+
+
+def cinds(N: int, k_trans: int):
+    """src/nlp.jl:48-63: seven 1-based inclusive (start, end) ranges."""
+    out, e = [], 0
+    for ln in (n, n - 1, (N - 1) * n, N, N - k_trans + 1, 1, N):
+        out.append((e + 1, e + ln))
+        e += ln
+    return out
+
+
+def constraint_bounds(N: int, k_trans: int):
+    """src/nlp.jl:66-69"""
+    ci = cinds(N, k_trans)
+    m_nlp = ci[-1][-1]
+    lb, ub = np.zeros(m_nlp), np.zeros(m_nlp)
+    ub[ci[6][0] - 1 : ci[6][1]] = np.inf
+    return lb, ub
+
+
+def packZ(N: int, X, U):
+    """src/nlp.jl:94-102.  X: (...,N,15), U: (...,N-1,5) -> Z (...,20N-5)."""
+    X = np.asarray(X, dtype=np.float64)
+    U = np.asarray(U, dtype=np.float64)
+    Z = np.zeros(X.shape[:-2] + (num_primals(N),))
+    body = Z[..., : 20 * (N - 1)].reshape(X.shape[:-2] + (N - 1, 20))
+    body[..., :15] = X[..., : N - 1, :]
+    body[..., 15:] = U
+    Z[..., 20 * (N - 1) :] = X[..., N - 1, :]
+    return Z
+
+
+def unpackZ(N: int, Z):
+    """src/nlp.jl:110-114"""
+    Z = np.asarray(Z)
+    body = Z[..., : 20 * (N - 1)].reshape(Z.shape[:-1] + (N - 1, 20))
+    X = np.concatenate([body[..., :15], Z[..., None, 20 * (N - 1) :]], axis=-2)
+    return X, body[..., 15:]
+
+
+# ----------------------------------------------------------------------------- evaluator
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class HybridNLP:
+    """Batch of B landing problems with a common horizon N on one GPU.
+
+    Constructor arguments follow HybridNLP(model, obj, init_mode, k_trans, N, x0, xf)
+    (src/nlp.jl:34-37); `obj` is the 41-double cost table of quadratic_cost.lqr_objective,
+    either (N,41) shared by all problems or (B,N,41).  Scalars broadcast over the batch.
+    """
+
+    def __init__(self, model: PlanarQuadruped, obj, init_mode, k_trans, N: int, x0, xf, *,
+                 device: int = 0, z_stride: int = 0, align: int = 16, stream=None):
+        self.model = model
+        self.N = int(N)
+        x0 = np.asarray(x0, dtype=np.float64)
+        B = x0.shape[0] if x0.ndim == 2 else 1
+        self.B = B
+        self.x0 = np.ascontiguousarray(np.broadcast_to(x0, (B, n)))
+        self.xf = np.ascontiguousarray(np.broadcast_to(np.asarray(xf, dtype=np.float64), (B, n)))
+        self.k_trans = np.ascontiguousarray(np.broadcast_to(np.asarray(k_trans, dtype=np.int32), (B,)))
+        self.init_mode = np.ascontiguousarray(np.broadcast_to(np.asarray(init_mode, dtype=np.int32), (B,)))
+        obj = np.ascontiguousarray(obj, dtype=np.float64)
+        if obj.shape == (self.N, _lib.COST_STRIDE):
+            self.cost_batch = 1
+        elif obj.shape == (B, self.N, _lib.COST_STRIDE):
+            self.cost_batch = B
+        else:
+            raise ValueError(f"obj must have shape (N,41) or (B,N,41), got {obj.shape}")
+        self.obj = obj
+        self.device = int(device)
+
+        L = _lib.lib()
+        d = _lib.QlnBatchDesc()
+        d.B, d.N = B, self.N
+        d.model = _lib.QlnModel(model.g, model.mb, model.mf, model.lb, model.l1, model.l2)
+        ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        d.k_trans = self.k_trans.ctypes.data_as(ip)
+        d.init_mode = self.init_mode.ctypes.data_as(ip)
+        d.x0, d.xf, d.cost = self.x0.ctypes.data_as(dp), self.xf.ctypes.data_as(dp), self.obj.ctypes.data_as(dp)
+        d.cost_batch, d.z_stride, d.align = self.cost_batch, int(z_stride), int(align)
+        h = C.c_void_p()
+        _lib.check(L.qln_create(C.byref(d), self.device, C.byref(h)))
+        self._h = h
+        dims = _lib.QlnDims()
+        _lib.check(L.qln_get_dims(self._h, C.byref(dims)))
+        self.dims = dims
+        self.n_nlp, self.z_stride = dims.n_nlp, dims.z_stride
+        self.nnz_dynamic = dims.nnz_dynamic
+        self.c_off = np.zeros(B, dtype=np.int64)
+        self.j_off = np.zeros(B, dtype=np.int64)
+        lp = C.POINTER(C.c_int64)
+        _lib.check(L.qln_get_offsets(self._h, self.c_off.ctypes.data_as(lp), self.j_off.ctypes.data_as(lp)))
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().qln_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """`stream`: a torch.cuda.Stream or a raw hipStream_t address."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        _lib.check(_lib.lib().qln_set_stream(self._h, C.c_void_p(int(ptr))))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().qln_synchronize(self._h))
+
+    # -- sizes / index maps (src/nlp.jl:85-87) ------------------------------------------------
+    def num_primals(self) -> int:
+        return self.n_nlp
+
+    def num_duals(self, b: int = 0) -> int:
+        mm, _ = self.problem_dims(b)
+        return mm
+
+    def size(self):
+        return (n, m, self.N)
+
+    def problem_dims(self, b: int = 0):
+        mm, nz = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().qln_problem_dims(self._h, b, C.byref(mm), C.byref(nz)))
+        return mm.value, nz.value
+
+    def cinds(self, b: int = 0):
+        out = (C.c_int32 * 14)()
+        _lib.check(_lib.lib().qln_constraint_index_ranges(self._h, b, out))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(7)]
+
+    def bounds(self, b: int = 0):
+        """(lb, ub) of problem b, src/nlp.jl:66-69."""
+        mm, _ = self.problem_dims(b)
+        lb, ub = np.empty(mm), np.empty(mm)
+        _lib.check(_lib.lib().qln_constraint_bounds(self._h, b, lb.ctypes.data, ub.ctypes.data))
+        return lb, ub
+
+    def jacobian_structure(self, b: int = 0):
+        """0-based (rows, cols) of problem b's block-COO values."""
+        _, nz = self.problem_dims(b)
+        rows, cols = np.zeros(nz, dtype=np.int32), np.zeros(nz, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        _lib.check(_lib.lib().qln_jacobian_structure(self._h, b, rows.ctypes.data_as(ip), cols.ctypes.data_as(ip)))
+        return rows, cols
+
+    # -- device buffers -------------------------------------------------------------------------
+    def _dev(self):
+        return _torch().device("cuda", self.device)
+
+    def new_Z(self):
+        return _torch().zeros(self.dims.z_total, dtype=_torch().float64, device=self._dev())
+
+    def new_c(self):
+        return _torch().zeros(self.dims.c_total, dtype=_torch().float64, device=self._dev())
+
+    def new_vals(self):
+        return _torch().zeros(self.dims.j_total, dtype=_torch().float64, device=self._dev())
+
+    def new_f(self):
+        return _torch().zeros(self.B, dtype=_torch().float64, device=self._dev())
+
+    def upload_Z(self, Z_host):
+        """Z_host: (B, n_nlp) -> device buffer in the handle's z_stride layout."""
+        t = _torch()
+        Z_host = np.asarray(Z_host, dtype=np.float64).reshape(self.B, self.n_nlp)
+        buf = np.zeros((self.B, self.z_stride))
+        buf[:, : self.n_nlp] = Z_host
+        return t.from_numpy(buf.reshape(-1)).to(self._dev())
+
+    def _check(self, t, total, name):
+        T = _torch()
+        if not (isinstance(t, T.Tensor) and t.is_cuda and t.dtype == T.float64 and t.is_contiguous()):
+            raise TypeError(f"{name} must be a contiguous float64 CUDA tensor")
+        if t.device.index != self.device:
+            raise ValueError(f"{name} is on cuda:{t.device.index}, handle is on cuda:{self.device}")
+        if t.numel() < total:
+            raise ValueError(f"{name} has {t.numel()} elements, need {total}")
+        return C.c_void_p(t.data_ptr())
+
+    # -- evaluation (device tensors, stream-ordered) ----------------------------------------------
+    def eval_f(self, Z, out=None):
+        """src/costs.jl:6-16 for every problem -> (B,) tensor."""
+        out = self.new_f() if out is None else out
+        _lib.check(_lib.lib().qln_eval_objective(self._h, self._check(Z, self.dims.z_total, "Z"), self._check(out, self.B, "f")))
+        return out
+
+    def grad_f(self, Z, out=None):
+        """src/costs.jl:23-34 -> tensor laid out like Z."""
+        out = self.new_Z() if out is None else out
+        _lib.check(_lib.lib().qln_eval_objective_gradient(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(out, self.dims.z_total, "grad")))
+        return out
+
+    def eval_c(self, Z, out=None):
+        """src/constraints.jl:145-158 -> c buffer (problem b at c_off[b])."""
+        out = self.new_c() if out is None else out
+        _lib.check(_lib.lib().qln_eval_constraint(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(out, self.dims.c_total, "c")))
+        return out
+
+    def jac_c(self, Z, out=None, write_constants: bool = True):
+        """src/constraints.jl:212-291 -> block-COO values (problem b at j_off[b])."""
+        out = self.new_vals() if out is None else out
+        flags = _lib.QLN_JAC_WRITE_CONSTANTS if write_constants else 0
+        _lib.check(_lib.lib().qln_eval_constraint_jacobian(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(out, self.dims.j_total, "vals"), flags))
+        return out
+
+    def eval_c_and_jac(self, Z, c=None, vals=None, write_constants: bool = True):
+        """The fused hot path: eval_c! + jac_c! in one launch."""
+        c = self.new_c() if c is None else c
+        vals = self.new_vals() if vals is None else vals
+        flags = _lib.QLN_JAC_WRITE_CONSTANTS if write_constants else 0
+        _lib.check(_lib.lib().qln_eval_constraint_and_jacobian(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(c, self.dims.c_total, "c"),
+            self._check(vals, self.dims.j_total, "vals"), flags))
+        return c, vals
+
+    def init_jacobian_constants(self, vals):
+        _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
+        return vals
+
+    def time_c_and_jac(self, Z, c, vals, warmup: int, iters: int, write_constants: bool = False):
+        """HIP-event duration (ms) of each of `iters` launches of the fused hot path."""
+        ms = (C.c_float * iters)()
+        flags = _lib.QLN_JAC_WRITE_CONSTANTS if write_constants else 0
+        _lib.check(_lib.lib().qln_time_constraint_and_jacobian(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(c, self.dims.c_total, "c"),
+            self._check(vals, self.dims.j_total, "vals"), flags, warmup, iters, ms))
+        return np.array(ms[:], dtype=np.float64)
+
+    # -- host-pointer (MOI) mode ------------------------------------------------------------------
+    def _host_Z(self, Z):
+        Z = np.asarray(Z, dtype=np.float64)
+        if Z.size == self.B * self.n_nlp and self.z_stride != self.n_nlp:
+            buf = np.zeros((self.B, self.z_stride))
+            buf[:, : self.n_nlp] = Z.reshape(self.B, self.n_nlp)
+            Z = buf
+        Z = np.ascontiguousarray(Z.reshape(-1))
+        if Z.size != self.dims.z_total:
+            raise ValueError(f"Z has {Z.size} entries, expected {self.dims.z_total}")
+        return Z
+
+    def eval_f_host(self, Z):
+        Z = self._host_Z(Z)
+        f = np.zeros(self.B)
+        _lib.check(_lib.lib().qln_eval_objective_host(self._h, Z.ctypes.data, f.ctypes.data))
+        return f
+
+    def grad_f_host(self, Z):
+        Z = self._host_Z(Z)
+        g = np.zeros(self.dims.z_total)
+        _lib.check(_lib.lib().qln_eval_objective_gradient_host(self._h, Z.ctypes.data, g.ctypes.data))
+        return g
+
+    def eval_c_host(self, Z):
+        Z = self._host_Z(Z)
+        c = np.zeros(self.dims.c_total)
+        _lib.check(_lib.lib().qln_eval_constraint_host(self._h, Z.ctypes.data, c.ctypes.data))
+        return c
+
+    def jac_c_host(self, Z):
+        Z = self._host_Z(Z)
+        v = np.zeros(self.dims.j_total)
+        _lib.check(_lib.lib().qln_eval_constraint_jacobian_host(self._h, Z.ctypes.data, v.ctypes.data))
+        return v
+
+    def jac_c_dense_host(self, Z_b, jac, b: int = 0):
+        """Reference-compatible dense Jacobian of problem b: `jac` is a Fortran-ordered
+        (m_nlp, n_nlp) float64 array; only the jac_c! write-set is assigned."""
+        Z_b = np.ascontiguousarray(Z_b, dtype=np.float64)
+        mm, _ = self.problem_dims(b)
+        if Z_b.size != self.n_nlp:
+            raise ValueError("Z_b must hold one problem's n_nlp entries")
+        if not (jac.dtype == np.float64 and jac.flags.f_contiguous and jac.shape == (mm, self.n_nlp)):
+            raise ValueError("jac must be a Fortran-ordered float64 (m_nlp, n_nlp) array")
+        _lib.check(_lib.lib().qln_eval_constraint_jacobian_dense_host(self._h, b, Z_b.ctypes.data, jac.ctypes.data))
+        return jac
+
+    # -- views ------------------------------------------------------------------------------------
+    def split_c(self, c_host, b: int = 0):
+        mm, _ = self.problem_dims(b)
+        return np.asarray(c_host)[self.c_off[b] : self.c_off[b] + mm]
+
+    def split_vals(self, vals_host, b: int = 0):
+        _, nz = self.problem_dims(b)
+        return np.asarray(vals_host)[self.j_off[b] : self.j_off[b] + nz]

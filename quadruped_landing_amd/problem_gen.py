@@ -1,0 +1,126 @@
+"""Synthetic batched landing problems (SURVEY.md 8d / BASELINE.md 5).
+
+The step before the hot path: per-problem random drop states around the notebook's
+initial condition (src/main.ipynb:114-124), the notebook's terminal state (:129-132),
+cost (:152-161), reference trajectory (src/ref_traj.jl) and initial-guess rule
+(src/main.ipynb:181-198) plus noise, so that no structural zero makes the Jacobian
+artificially cheap.  Deterministic: numpy.random.default_rng(seed) (PCG64).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .nlp import packZ
+from .planar_quadruped import PlanarQuadruped
+from .quadratic_cost import lqr_objective
+from .ref_traj import reference_trajectory
+
+Q_DIAG = np.array([10.0] * 14 + [0.0])              # src/main.ipynb:152
+R_DIAG = np.array([1e-3, 1e-2, 1e-3, 1e-2, 0.0])    # src/main.ipynb:153
+
+
+@dataclass
+class LandingBatch:
+    model: PlanarQuadruped
+    N: int
+    k_trans: np.ndarray    # (B,) int32
+    init_mode: np.ndarray  # (B,) int32
+    x0: np.ndarray         # (B,15)
+    xf: np.ndarray         # (B,15)
+    obj: np.ndarray        # (N,41) or (B,N,41)
+    Z: np.ndarray          # (B, 20N-5)
+
+    @property
+    def B(self):
+        return self.x0.shape[0]
+
+
+def terminal_state(model: PlanarQuadruped):
+    """xterm, src/main.ipynb:129-132"""
+    xterm = np.zeros(15)
+    xterm[0] = -model.lb / 2
+    xterm[1] = np.sqrt(model.l1**2 + model.l2**2)
+    xterm[5] = -model.lb
+    return xterm
+
+
+def notebook_initial_state(model: PlanarQuadruped, theta0_deg=-30.0, drop_h=2.0):
+    """xinit, src/main.ipynb:92-124"""
+    x = np.zeros(15)
+    x[0] = -model.lb / 2.5
+    x[1] = np.sqrt(model.l1**2 + model.l2**2) + 0.1
+    x[2] = theta0_deg * np.pi / 180
+    x[5] = -model.lb
+    x[6] = 0.2
+    x[8] = -np.sqrt(2 * 9.81 * drop_h)
+    x[9] = -np.pi / 2
+    x[13] = -1.0
+    return x
+
+
+def initial_guess(N, k_trans, x0, xf, Uref):
+    """Notebook initial-guess rule (src/main.ipynb:181-198) + packZ, vectorised over the batch.
+    x0, xf: (B,15); k_trans: (B,); Uref: (B,N-1,5) -> Z (B, 20N-5)."""
+    B = x0.shape[0]
+    K = np.arange(1, N + 1)[None, :, None]               # 1-based knot
+    kt = np.asarray(k_trans)[:, None, None]
+    ramp = x0[:, None, :] + (xf - x0)[:, None, :] / (kt - 1) * (K - 1)
+    X = np.where(K <= kt, ramp, 0.0)
+    after = np.broadcast_to(K > kt, X.shape).copy()
+    after[:, :, 14] = False
+    X = np.where(after, np.broadcast_to(xf[:, None, :], X.shape), X)
+    dtk = np.where(np.arange(1, N)[None, :] < np.asarray(k_trans)[:, None], 0.001, 0.02)
+    X[:, 1:, 14] = X[:, :1, 14] + np.cumsum(dtk, axis=1)
+    return packZ(N, X, Uref)
+
+
+def make_batch(B: int, N: int = 40, k_trans=14, init_mode=1, *, seed: int = 0, ragged: bool = False,
+               noise: float = 0.05, dt: float = 0.009, model: PlanarQuadruped | None = None) -> LandingBatch:
+    """BASELINE.json configs 2/3/5 (uniform k_trans/init_mode) or config 4 (ragged=True:
+    per-problem k_trans ~ U{2..N-1}, init_mode ~ U{1,2}, h ~ U(0.001, 0.02))."""
+    model = model or PlanarQuadruped()
+    rng = np.random.default_rng(seed)
+    if ragged:
+        kt = rng.integers(2, N, size=B).astype(np.int32)         # U{2..N-1}
+        im = rng.integers(1, 3, size=B).astype(np.int32)
+    else:
+        kt = np.full(B, k_trans, dtype=np.int32)
+        im = np.full(B, init_mode, dtype=np.int32)
+    x0 = np.tile(notebook_initial_state(model), (B, 1))
+    x0[:, 2] = np.deg2rad(rng.uniform(-40.0, -10.0, size=B))
+    x0[:, 6] = rng.uniform(0.1, 0.3, size=B)
+    x0[:, 8] = -np.sqrt(2 * 9.81 * rng.uniform(0.5, 2.5, size=B))
+    x0[:, 9] = rng.uniform(-np.pi / 2, 0.0, size=B)
+    swap = im == 2                                              # mirror the feet for init_mode 2
+    x0[swap, 3:5], x0[swap, 5:7] = x0[swap, 5:7].copy(), x0[swap, 3:5].copy()
+    x0[swap, 10:12], x0[swap, 12:14] = x0[swap, 12:14].copy(), x0[swap, 10:12].copy()
+    xf = np.tile(terminal_state(model), (B, 1))
+    Xref, Uref = reference_trajectory(model, N, kt, xf, im, dt)
+    if ragged:
+        obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref, Uref)
+    else:
+        obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref[0], Uref[0])
+    Z = initial_guess(N, kt, x0, xf, Uref)
+    Z += rng.normal(0.0, noise, size=Z.shape)
+    hcols = 19 + 20 * np.arange(N - 1)
+    if ragged:
+        Z[:, hcols] = rng.uniform(0.001, 0.02, size=(B, N - 1))
+    else:
+        Z[:, hcols] = np.clip(Z[:, hcols], 0.001, 0.02)
+    return LandingBatch(model, N, kt, im, x0, xf, obj, Z)
+
+
+def notebook_problem(N: int = 61, k_trans: int = 21, init_mode: int = 1, dt: float = 0.009,
+                     model: PlanarQuadruped | None = None) -> LandingBatch:
+    """The literal notebook problem (src/main.ipynb cells 2-8) as a batch of one, Z = Z0."""
+    model = model or PlanarQuadruped()
+    x0 = notebook_initial_state(model)[None, :]
+    xf = terminal_state(model)[None, :]
+    kt = np.array([k_trans], dtype=np.int32)
+    im = np.array([init_mode], dtype=np.int32)
+    Xref, Uref = reference_trajectory(model, N, kt, xf, im, dt)
+    obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref[0], Uref[0])
+    Z = initial_guess(N, kt, x0, xf, Uref)
+    return LandingBatch(model, N, kt, im, x0, xf, obj, Z)
