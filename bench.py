@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- knot-point constraint+Jacobian evals/sec of the fused HIP hot path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A step = one launch of eval_c! + jac_c! over every knot of every problem of the rank's shard, with
+inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2] (B=65536, N=40,
+k_trans=14, FP64): the HBM-bound regime the metric's roofline half is quoted on; configs[1]
+(B=1024, launch-latency regime) is timed beside it and reported under "other".
+Multi-GPU: weak scaling, one process per GPU, the shard is generated locally, no data-path
+collective; one RCCL gather of (f, c) to rank 0 after the K steps, inside the timed region.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    "config2": dict(B=1024, N=40, k_trans=14, ragged=False, desc="B=1024 N=40 k_trans=14 init_mode=1 FP64"),
+    "config3": dict(B=65536, N=40, k_trans=14, ragged=False, desc="B=65536 N=40 k_trans=14 init_mode=1 FP64"),
+    "config4": dict(B=65536, N=80, k_trans=0, ragged=True, desc="B=65536 N=80 per-problem k_trans~U{2..79}, init_mode~U{1,2} FP64"),
+}
+
+
+def algorithmic_bytes(N, k_trans):
+    """read Z + write c + write state-dependent Jacobian values, per problem."""
+    k_trans = np.asarray(k_trans, dtype=np.int64)
+    return 8 * (20 * N - 5) + 8 * (18 * N - k_trans + 16) + 8 * (300 * (N - 1) + N)
+
+
+def build(workload, seed, device):
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    w = WORKLOADS[workload]
+    batch = PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=seed, ragged=w["ragged"])
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                    device=device, stream=torch.cuda.current_stream())
+    Z = nlp.upload_Z(batch.Z)
+    c, vals = nlp.new_c(), nlp.new_vals()
+    nlp.init_jacobian_constants(vals)  # constants are written once at setup
+    return batch, nlp, Z, c, vals
+
+
+def cpu_baseline(batch, nlp, budget_s=12.0):
+    """Oracle (C restatement of the reference algorithm, 1 thread) on a bounded sample of the SAME
+    workload.  Reported baseline, not the target."""
+    from tests.helpers import oracle_model
+    from oracle import oracle as O
+
+    def run(nb, nthreads):
+        Zs = np.zeros((nb, nlp.z_stride))
+        Zs[:, : nlp.n_nlp] = batch.Z[:nb]
+        obj = batch.obj if batch.obj.ndim == 2 else batch.obj[:nb]
+        c_off = nlp.c_off[:nb] - nlp.c_off[0]
+        j_off = nlp.j_off[:nb] - nlp.j_off[0]
+        c_total = int(c_off[-1] + nlp.dims.m_nlp_max + 16)
+        j_total = int(j_off[-1] + nlp.dims.nnz_max + 16)
+        t0 = time.perf_counter()
+        O.batch_eval(batch.N, oracle_model(batch.model), batch.k_trans[:nb], batch.init_mode[:nb], batch.x0[:nb],
+                     batch.xf[:nb], obj, Zs.reshape(-1), nlp.z_stride, c_off, j_off, c_total, j_total,
+                     True, True, False, False, nthreads)
+        return time.perf_counter() - t0
+
+    probe = min(256, batch.B)
+    t = run(probe, 1)
+    nb = int(min(batch.B, max(probe, probe * budget_s / max(t, 1e-6))))
+    t1 = run(nb, 1)
+    one = {"value": nb * batch.N / t1, "unit": "knot-evals/s", "cores": 1, "kind": "port",
+           "sample": f"{nb} problems x N={batch.N} ({nb * batch.N} knot evals, {t1:.1f} s) of the same synthetic batch; "
+                     "C restatement of the reference algorithm (oracle/qln_oracle.c, forward-mode duals), not Julia"}
+    ncores = min(os.cpu_count() or 1, 16)
+    nb_all = int(min(batch.B, nb * min(ncores, 4)))
+    tall = run(nb_all, ncores)
+    allc = {"value": nb_all * batch.N / tall, "unit": "knot-evals/s", "cores": ncores, "kind": "port",
+            "sample": f"{nb_all} problems, OpenMP over problems, {tall:.1f} s"}
+    return one, allc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from quadruped_landing_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
+    batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank)
+    f = nlp.new_f()
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # warmup (untimed): W launches, one objective pass, and one gather so RCCL is initialised
+    nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
+    nlp.eval_f(Z, f)
+    if world > 1:
+        D.gather_results(f, c)
+    barrier()
+
+    t0 = time.perf_counter()
+    ms_each = nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=K)  # K launches, HIP events around each
+    t_gather = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        nlp.eval_f(Z, f)
+        D.gather_results(f, c)  # the single end-of-job exchange (RCCL over xGMI)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    t_gather = D.max_over_ranks(t_gather, dev)
+
+    knots_per_step = batch.B * batch.N * world
+    value = knots_per_step * K / elapsed
+
+    alg_bytes = float(np.sum(algorithmic_bytes(batch.N, batch.k_trans)))
+    avg_ms = float(np.mean(ms_each))
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "knot-point constraint+Jacobian evals/sec",
+        "value": value,
+        "unit": "knot-evals/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1])}]: {WORKLOADS[args.workload]['desc']}; "
+                               "per-rank shard, constants of the Jacobian pre-written",
+                   "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride)},
+    }
+    if rank == 0:
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms,
+                           "launch_ms_min": float(np.min(ms_each)), "algorithmic_bytes_per_launch": alg_bytes,
+                           "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N)}
+        if world > 1:
+            out["gather_ms"] = t_gather * 1e3
+        if world == 1 and not args.no_other and args.workload != "config2":
+            b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank)
+            ms2 = n2.time_c_and_jac(Z2, c2, v2, warmup=5, iters=50)
+            out["other"] = {"config2_B1024_N40": {"launch_ms_avg": float(np.mean(ms2)),
+                                                   "knot_evals_per_s": b2.B * b2.N / (float(np.mean(ms2)) * 1e-3)}}
+            del b2, n2, Z2, c2, v2
+        if world == 1 and not args.no_cpu_baseline:
+            one, allc = cpu_baseline(batch, nlp)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = allc
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
