@@ -30,6 +30,17 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kBlk = 300;  // 15 x 20 doubles per step block
 
+// Every workgroup of the hot kernel is ONE wavefront, so cross-lane hand-offs through LDS need no
+// s_barrier: the LDS executes a wave's DS instructions in issue order.  What is needed is that the
+// compiler keeps that order; a wavefront-scope fence plus the (instruction-less) wave barrier do
+// that.  Unlike __syncthreads() this does not drain vmcnt, so the global store stream of one
+// sub-tile keeps flowing while the next one is assembled.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Value path: literal restatement of contact{1,2,3}_dynamics (src/planar_quadruped.jl:36-185).
 // f1free/f2free select the mode: mode 1 = foot 2 free, mode 2 = foot 1 free, mode 3 = none.
@@ -93,10 +104,12 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
                                                               double* __restrict__ C, double* __restrict__ V,
                                                               uint32_t flags) {
     static_assert(T * kBlk >= kWave * 20 + 15, "Z slice of one 64-knot chunk must fit in the Jacobian tile it aliases");
-    __shared__ double2 s_j2[T * kBlk / 2];  // T dense step blocks; aliased by the staged Z slice
-    __shared__ double s_c[T * 15];
+    // T dense step blocks.  Before the Jacobian phase of a chunk the same LDS first holds the staged
+    // Z slice (20*64+15 doubles) and then the chunk's dynamics residuals (64*15 doubles).
+    __shared__ double2 s_j2[T * kBlk / 2];
     double* const s_j = reinterpret_cast<double*>(s_j2);
     double* const s_z = s_j;
+    double* const s_c = s_j;
 
     const int lane = threadIdx.x;
     const int b = b_begin + blockIdx.x;
@@ -155,9 +168,9 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
     for (int kc0 = 0; kc0 < N - 1; kc0 += kWave) {
         const int nk = min(kWave, N - 1 - kc0);
         const int nz = 20 * nk + 15;
-        __syncthreads();  // previous chunk's drain has finished reading the tile
+        wave_lds_sync();  // previous chunk's drain reads precede this chunk's staging writes
         for (int i = lane; i < nz; i += kWave) s_z[i] = Zb[20 * kc0 + i];
-        __syncthreads();
+        wave_lds_sync();
 
         const bool valid = lane < nk;
         const int k = kc0 + lane;  // 0-based dynamics knot; K = k + 1 in the reference's numbering
@@ -171,12 +184,7 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
 #pragma unroll
             for (int i = 0; i < 15; ++i) xnext[i] = zl[20 + i];
         }
-        __syncthreads();
-        if (WITH_J) {
-            // structural zeros of the tile: written here, never touched by the value writes below
-            const double2 zero2 = make_double2(0.0, 0.0);
-            for (int i = lane; i < T * kBlk / 2; i += kWave) s_j2[i] = zero2;
-        }
+        wave_lds_sync();
 
         // mode schedule, src/constraints.jl:23-37: K < k_trans-1 -> init mode; K == k_trans-1 ->
         // init mode then jump map; else mode 3
@@ -195,9 +203,8 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
         sc.a2x = f2free ? (-F2x / mf) : 0.0;
         sc.a2y = f2free ? (-F2y / mf + g) : 0.0;
 
-        double cd[15];
         if (WITH_C) {
-            double xn[15];
+            double xn[15], cd[15];
             rk4_step(x, u, sc, f1free, f2free, Ib, xn);
             if (jump) {  // jump1_map / jump2_map, src/planar_quadruped.jl:250-260
                 xn[4] = 0.0;
@@ -217,6 +224,28 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
                     if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = xnext[a_other == 4 ? 4 : 6];
                     Cb[o_bp + k + 1] = xnext[1] - lb / 2 * fabs(sin(xnext[2]));
                 }
+            }
+            // dynamics residuals: 15 per knot, knot-major and contiguous in c (src/constraints.jl:14-18);
+            // transposed through LDS so the store is coalesced
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 15; ++i) s_c[lane * 15 + i] = cd[i];
+            }
+            wave_lds_sync();
+            {
+                double* __restrict__ dst = Cb + o_dyn + 15 * kc0;
+                const int np = nk * 15;
+                for (int i = lane; i < np; i += kWave) dst[i] = s_c[i];
+            }
+            wave_lds_sync();
+        }
+        if (WITH_J) {
+            // structural zeros of the tile: written here, never touched by the value writes below
+            const double2 zero2 = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int it = 0; it < (T * kBlk / 2 + kWave - 1) / kWave; ++it) {
+                const int i = it * kWave + lane;
+                if (i < T * kBlk / 2) s_j2[i] = zero2;
             }
         }
 
@@ -351,10 +380,6 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
             const int nkt = min(T, nk - t * T);   // knots in it
             if (valid && (lane / T) == t) {
                 const int r = lane - t * T;
-                if (WITH_C) {
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) s_c[r * 15 + i] = cd[i];
-                }
                 if (WITH_J) {
                     double* jr = s_j + r * kBlk;
 #define JW(row, col, idx) jr[(row) + 15 * (col)] = jv[idx]
@@ -380,20 +405,18 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
 #undef JW
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
             if (WITH_J) {
                 // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
                 double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
                 const int np = nkt * (kBlk / 2);
-#pragma unroll 4
-                for (int i = lane; i < np; i += kWave) dst[i] = s_j2[i];
+#pragma unroll
+                for (int it = 0; it < (T * kBlk / 2 + kWave - 1) / kWave; ++it) {
+                    const int i = it * kWave + lane;
+                    if (i < np) dst[i] = s_j2[i];
+                }
             }
-            if (WITH_C) {
-                double* __restrict__ dst = Cb + o_dyn + 15 * kb;
-                const int np = nkt * 15;
-                for (int i = lane; i < np; i += kWave) dst[i] = s_c[i];
-            }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 }
