@@ -132,19 +132,6 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
     const int a_init = (im == 1) ? 4 : 6;  // y of the initially touching foot
     const int a_other = (im == 1) ? 6 : 4;
 
-    if (WITH_C) {
-        // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
-        // c6 = F1y + F2y + mb*g of u_{N-1} (:154)
-        if (lane < 15) {
-            Cb[lane] = Zb[lane] - P.x0[(int64_t)b * 15 + lane];
-        } else if (lane < 29) {
-            const int i = lane - 15;
-            Cb[lane] = Zb[20 * (N - 1) + i] - P.xf[(int64_t)b * 15 + i];
-        } else if (lane == 29) {
-            const double* ul = Zb + 20 * (N - 2) + 15;
-            Cb[o_fc] = ul[1] + ul[3] + mb * g;
-        }
-    }
     if (WITH_J && (flags & 1u)) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
         double* Vc = Vb + kBlk * (N - 1) + N;
@@ -168,9 +155,41 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
     for (int kc0 = 0; kc0 < N - 1; kc0 += kWave) {
         const int nk = min(kWave, N - 1 - kc0);
         const int nz = 20 * nk + 15;
+        const bool first_chunk = (kc0 == 0);
+        const bool last_chunk = (kc0 + nk == N - 1);
+
+        // Stage the chunk's slice of Z: every load is issued before the first wait (one HBM round
+        // trip per chunk, not one per 512 B).  Indices past the slice are clamped, not predicated.
+        constexpr int kStageIters = (kWave * 20 + 15 + kWave - 1) / kWave;  // 21
+        double zr[kStageIters];
+        {
+            const double* __restrict__ zsrc = Zb + 20 * kc0;
+#pragma unroll
+            for (int it = 0; it < kStageIters; ++it) {
+                if (it * kWave < nz) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
+            }
+        }
+        // boundary data for c1 / c2 (src/constraints.jl:149-150), fetched with the same round trip
+        double bnd = 0.0;
+        if (WITH_C) {
+            if (first_chunk && lane < 15) bnd = P.x0[(int64_t)b * 15 + lane];
+            if (last_chunk && lane >= 15 && lane < 29) bnd = P.xf[(int64_t)b * 15 + (lane - 15)];
+        }
         wave_lds_sync();  // previous chunk's drain reads precede this chunk's staging writes
-        for (int i = lane; i < nz; i += kWave) s_z[i] = Zb[20 * kc0 + i];
+#pragma unroll
+        for (int it = 0; it < kStageIters; ++it) {
+            if (it * kWave < nz) s_z[it * kWave + lane] = zr[it];
+        }
         wave_lds_sync();
+        if (WITH_C) {
+            // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
+            // c6 = F1y + F2y + mb*g of u_{N-1} (:154), all out of the staged slice
+            if (first_chunk && lane < 15) Cb[lane] = s_z[lane] - bnd;
+            if (last_chunk) {
+                if (lane >= 15 && lane < 29) Cb[lane] = s_z[20 * nk + (lane - 15)] - bnd;
+                if (lane == 29) Cb[o_fc] = s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g;
+            }
+        }
 
         const bool valid = lane < nk;
         const int k = kc0 + lane;  // 0-based dynamics knot; K = k + 1 in the reference's numbering
@@ -235,7 +254,14 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
             {
                 double* __restrict__ dst = Cb + o_dyn + 15 * kc0;
                 const int np = nk * 15;
-                for (int i = lane; i < np; i += kWave) dst[i] = s_c[i];
+                double cr[15];
+#pragma unroll
+                for (int it = 0; it < 15; ++it) cr[it] = s_c[min(it * kWave + lane, kWave * 15 - 1)];
+#pragma unroll
+                for (int it = 0; it < 15; ++it) {
+                    const int i = it * kWave + lane;
+                    if (i < np) dst[i] = cr[it];
+                }
             }
             wave_lds_sync();
         }
@@ -248,6 +274,9 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
                 if (i < T * kBlk / 2) s_j2[i] = zero2;
             }
         }
+
+        // keep the Jacobian arithmetic from being hoisted into the RK4 phase (register pressure)
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- the 85 non-zeros of the step block, closed form (see header) ---------------------
         double jv[85];
@@ -410,10 +439,37 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
                 // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
                 double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
                 const int np = nkt * (kBlk / 2);
+                constexpr int kPieces = T * kBlk / 2;              // 16-byte pieces in a full tile
+                constexpr int kFull = kPieces / kWave;             // unpredicated wave instructions
+                constexpr int kGroup = 6;                          // LDS reads in flight per batch
+                if (nkt == T) {
+                    // full tile: batches of kGroup ds_read_b128 then kGroup 1-KiB stores
 #pragma unroll
-                for (int it = 0; it < (T * kBlk / 2 + kWave - 1) / kWave; ++it) {
-                    const int i = it * kWave + lane;
-                    if (i < np) dst[i] = s_j2[i];
+                    for (int g0 = 0; g0 < kFull; g0 += kGroup) {
+                        double2 r[kGroup];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j)
+                            if (g0 + j < kFull) r[j] = s_j2[(g0 + j) * kWave + lane];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j)
+                            if (g0 + j < kFull) dst[(g0 + j) * kWave + lane] = r[j];
+                    }
+                    if (kPieces % kWave) {
+                        const int i = kFull * kWave + lane;
+                        if (i < kPieces) dst[i] = s_j2[i];
+                    }
+                } else {
+#pragma unroll 1
+                    for (int g0 = 0; g0 * kWave < np; g0 += kGroup) {
+                        double2 r[kGroup];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) r[j] = s_j2[min((g0 + j) * kWave + lane, kPieces - 1)];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) {
+                            const int i = (g0 + j) * kWave + lane;
+                            if (i < np) dst[i] = r[j];
+                        }
+                    }
                 }
             }
             wave_lds_sync();
