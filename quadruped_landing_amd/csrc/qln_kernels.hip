@@ -23,12 +23,31 @@
 // (src/planar_quadruped.jl:225-248) up to rounding.
 #include "qln_device.h"
 
+#include <cstdlib>
+
 namespace qln {
+
+#ifdef QLN_DIAG
+__device__ unsigned long long* g_stamps = nullptr;
+#endif
 
 namespace {
 
 constexpr int kWave = 64;
 constexpr int kBlk = 300;  // 15 x 20 doubles per step block
+
+// Diagnostic build only (-DQLN_DIAG, never the shipped library): per-wave s_memtime stamps at phase
+// boundaries, written to a buffer of their own (cdna_hip_programming.md section 7, In-kernel stamps).
+#ifdef QLN_DIAG
+#define QLN_STAMP(i)                                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define QLN_STAMP(i) do { } while (0)
+#endif
 
 // Every workgroup of the hot kernel is ONE wavefront, so cross-lane hand-offs through LDS need no
 // s_barrier: the LDS executes a wave's DS instructions in issue order.  What is needed is that the
@@ -99,20 +118,29 @@ __device__ __forceinline__ void rk4_step(const double (&x)[15], const double (&u
 // ---------------------------------------------------------------------------------------------
 // Fused constraint + Jacobian kernel.
 // ---------------------------------------------------------------------------------------------
-template <int T, bool WITH_C, bool WITH_J>
-__global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P, int32_t b_begin, const double* __restrict__ Z,
+// T  = knots assembled per LDS tile (tile = T*2400 B, the only LDS the kernel uses)
+// KC = knots per chunk = lanes that integrate a knot at a time (<= 64); the chunk's Z slice and
+//      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
+// W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
+template <int T, int KC, int W, bool WITH_C, bool WITH_J>
+__global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, const double* __restrict__ Z,
                                                               double* __restrict__ C, double* __restrict__ V,
                                                               uint32_t flags) {
-    static_assert(T * kBlk >= kWave * 20 + 15, "Z slice of one 64-knot chunk must fit in the Jacobian tile it aliases");
-    // T dense step blocks.  Before the Jacobian phase of a chunk the same LDS first holds the staged
-    // Z slice (20*64+15 doubles) and then the chunk's dynamics residuals (64*15 doubles).
+    // LDS: one tile of T dense step blocks.  Before the Jacobian phase of a chunk the same bytes
+    // hold the staged Z slice (20*64+15 doubles at offset 0) and, behind it, the chunk's dynamics
+    // residuals (64*15 doubles at offset kCStage).
+    static_assert(KC <= kWave, "one lane per knot of a chunk");
+    constexpr int kZSlice = KC * 20 + 15;
+    constexpr int kCStage = (kZSlice + 1) & ~1;
+    static_assert(T * kBlk >= kCStage + KC * 15, "Z slice + residual stage must fit in the tile they alias");
     __shared__ double2 s_j2[T * kBlk / 2];
     double* const s_j = reinterpret_cast<double*>(s_j2);
     double* const s_z = s_j;
-    double* const s_c = s_j;
+    double* const s_c = s_j + kCStage;
 
     const int lane = threadIdx.x;
     const int b = b_begin + blockIdx.x;
+    QLN_STAMP(0);
     const int N = P.N;
     const int kt = P.k_trans[b];
     const int im = P.init_mode[b];
@@ -129,8 +157,7 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
     const int o_co = o_ci + N;
     const int o_fc = o_co + (N - kt + 1);
     const int o_bp = o_fc + 1;
-    const int a_init = (im == 1) ? 4 : 6;  // y of the initially touching foot
-    const int a_other = (im == 1) ? 6 : 4;
+    const bool init1 = (im == 1);  // foot 1 touches first: contact-init row is y1, contact-other is y2
 
     if (WITH_J && (flags & 1u)) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
@@ -152,148 +179,156 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
         }
     }
 
-    for (int kc0 = 0; kc0 < N - 1; kc0 += kWave) {
-        const int nk = min(kWave, N - 1 - kc0);
+    for (int kc0 = 0; kc0 < N - 1; kc0 += KC) {
+        const int nk = min(KC, N - 1 - kc0);
         const int nz = 20 * nk + 15;
         const bool first_chunk = (kc0 == 0);
         const bool last_chunk = (kc0 + nk == N - 1);
+        const bool valid = lane < nk;
+        const int k = kc0 + lane;  // 0-based dynamics knot; K = k + 1 in the reference's numbering
+        const int K = k + 1;
+        // mode schedule, src/constraints.jl:23-37: K < k_trans-1 -> init mode; K == k_trans-1 ->
+        // init mode then jump map; else mode 3.  mode 1 = foot 2 free, mode 2 = foot 1 free.
+        const int mode = (K <= kt - 1) ? im : 3;
+        const bool jump = (K == kt - 1);
+        const bool f1free = (mode == 2);
+        const bool f2free = (mode == 1);
+        const double* zl = s_z + 20 * (valid ? lane : 0);
 
-        // Stage the chunk's slice of Z: every load is issued before the first wait (one HBM round
-        // trip per chunk, not one per 512 B).  Indices past the slice are clamped, not predicated.
-        constexpr int kStageIters = (kWave * 20 + 15 + kWave - 1) / kWave;  // 21
-        double zr[kStageIters];
+        // ---- stage the chunk's slice of Z: every load is issued before the first wait (one HBM
+        // round trip per chunk).  Indices past the slice are clamped, not predicated. -----------
         {
+            constexpr int kStageIters = (kZSlice + kWave - 1) / kWave;
+            double zr[kStageIters];
             const double* __restrict__ zsrc = Zb + 20 * kc0;
 #pragma unroll
             for (int it = 0; it < kStageIters; ++it) {
                 if (it * kWave < nz) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
             }
-        }
-        // boundary data for c1 / c2 (src/constraints.jl:149-150), fetched with the same round trip
-        double bnd = 0.0;
-        if (WITH_C) {
-            if (first_chunk && lane < 15) bnd = P.x0[(int64_t)b * 15 + lane];
-            if (last_chunk && lane >= 15 && lane < 29) bnd = P.xf[(int64_t)b * 15 + (lane - 15)];
-        }
-        wave_lds_sync();  // previous chunk's drain reads precede this chunk's staging writes
+            // boundary data for c1 / c2 (src/constraints.jl:149-150): unconditional and in bounds so
+            // it joins the same round trip
+            double bnd = 0.0;
+            if (WITH_C) {
+                const double* bp = (lane < 15) ? P.x0 + (int64_t)b * 15 + lane : P.xf + (int64_t)b * 15 + (min(lane, 28) - 15);
+                bnd = *bp;
+            }
+            wave_lds_sync();  // the previous chunk's drain reads precede this chunk's staging writes
 #pragma unroll
-        for (int it = 0; it < kStageIters; ++it) {
-            if (it * kWave < nz) s_z[it * kWave + lane] = zr[it];
-        }
-        wave_lds_sync();
-        if (WITH_C) {
-            // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
-            // c6 = F1y + F2y + mb*g of u_{N-1} (:154), all out of the staged slice
-            if (first_chunk && lane < 15) Cb[lane] = s_z[lane] - bnd;
-            if (last_chunk) {
-                if (lane >= 15 && lane < 29) Cb[lane] = s_z[20 * nk + (lane - 15)] - bnd;
-                if (lane == 29) Cb[o_fc] = s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g;
+            for (int it = 0; it < kStageIters; ++it) {
+                if (it * kWave < nz) s_z[it * kWave + lane] = zr[it];
+            }
+            wave_lds_sync();
+            if (WITH_C) {
+                // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
+                // c6 = F1y + F2y + mb*g of u_{N-1} (:154), all out of the staged slice
+                if (first_chunk && lane < 15) Cb[lane] = s_z[lane] - bnd;
+                if (last_chunk) {
+                    if (lane >= 15 && lane < 29) Cb[lane] = s_z[20 * nk + (lane - 15)] - bnd;
+                    if (lane == 29) Cb[o_fc] = s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g;
+                }
             }
         }
 
-        const bool valid = lane < nk;
-        const int k = kc0 + lane;  // 0-based dynamics knot; K = k + 1 in the reference's numbering
-        double x[15], u[5], xnext[15];
-        {
-            const double* zl = s_z + 20 * (valid ? lane : 0);
+        QLN_STAMP(1);
+        // ============================== value phase (eval_c!) ==================================
+        if (WITH_C) {
+            double x[15], u[5], xnext[15];
 #pragma unroll
             for (int i = 0; i < 15; ++i) x[i] = zl[i];
 #pragma unroll
             for (int i = 0; i < 5; ++i) u[i] = zl[15 + i];
 #pragma unroll
             for (int i = 0; i < 15; ++i) xnext[i] = zl[20 + i];
-        }
-        wave_lds_sync();
 
-        // mode schedule, src/constraints.jl:23-37: K < k_trans-1 -> init mode; K == k_trans-1 ->
-        // init mode then jump map; else mode 3
-        const int K = k + 1;
-        const int mode = (K <= kt - 1) ? im : 3;
-        const bool jump = (K == kt - 1);
-        const bool f1free = (mode == 2);
-        const bool f2free = (mode == 1);
-
-        const double F1x = u[0], F1y = u[1], F2x = u[2], F2y = u[3], h = u[4];
-        StepConst sc;
-        sc.abx = (F1x + F2x) / mb;
-        sc.aby = (F1y + F2y) / mb + g;
-        sc.a1x = f1free ? (-F1x / mf) : 0.0;
-        sc.a1y = f1free ? (-F1y / mf + g) : 0.0;
-        sc.a2x = f2free ? (-F2x / mf) : 0.0;
-        sc.a2y = f2free ? (-F2y / mf + g) : 0.0;
-
-        if (WITH_C) {
-            double xn[15], cd[15];
+            StepConst sc;
+            sc.abx = (u[0] + u[2]) / mb;
+            sc.aby = (u[1] + u[3]) / mb + g;
+            sc.a1x = f1free ? (-u[0] / mf) : 0.0;
+            sc.a1y = f1free ? (-u[1] / mf + g) : 0.0;
+            sc.a2x = f2free ? (-u[2] / mf) : 0.0;
+            sc.a2y = f2free ? (-u[3] / mf + g) : 0.0;
+            double xn[15];
             rk4_step(x, u, sc, f1free, f2free, Ib, xn);
             if (jump) {  // jump1_map / jump2_map, src/planar_quadruped.jl:250-260
                 xn[4] = 0.0;
                 xn[6] = 0.0;
                 xn[10] = xn[11] = xn[12] = xn[13] = 0.0;
             }
-#pragma unroll
-            for (int i = 0; i < 15; ++i) cd[i] = xn[i] - xnext[i];
-
             // per-knot scalar rows: contact (src/constraints.jl:48-91) and clearance (:98-113)
             if (valid) {
-                Cb[o_ci + k] = x[a_init == 4 ? 4 : 6];
-                if (K >= kt) Cb[o_co + (K - kt)] = x[a_other == 4 ? 4 : 6];
+                Cb[o_ci + k] = init1 ? x[4] : x[6];
+                if (K >= kt) Cb[o_co + (K - kt)] = init1 ? x[6] : x[4];
                 Cb[o_bp + k] = x[1] - lb / 2 * fabs(sin(x[2]));
                 if (k == N - 2) {  // this lane also holds the terminal knot x_N
-                    Cb[o_ci + k + 1] = xnext[a_init == 4 ? 4 : 6];
-                    if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = xnext[a_other == 4 ? 4 : 6];
+                    Cb[o_ci + k + 1] = init1 ? xnext[4] : xnext[6];
+                    if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = init1 ? xnext[6] : xnext[4];
                     Cb[o_bp + k + 1] = xnext[1] - lb / 2 * fabs(sin(xnext[2]));
                 }
-            }
-            // dynamics residuals: 15 per knot, knot-major and contiguous in c (src/constraints.jl:14-18);
-            // transposed through LDS so the store is coalesced
-            if (valid) {
+                // dynamics residuals: 15 per knot, knot-major and contiguous in c
+                // (src/constraints.jl:14-18); transposed through LDS so the store is coalesced
 #pragma unroll
-                for (int i = 0; i < 15; ++i) s_c[lane * 15 + i] = cd[i];
+                for (int i = 0; i < 15; ++i) s_c[lane * 15 + i] = xn[i] - xnext[i];
             }
             wave_lds_sync();
             {
                 double* __restrict__ dst = Cb + o_dyn + 15 * kc0;
                 const int np = nk * 15;
-                double cr[15];
+                constexpr int kCIters = (KC * 15 + kWave - 1) / kWave;
+                double cr[kCIters];
 #pragma unroll
-                for (int it = 0; it < 15; ++it) cr[it] = s_c[min(it * kWave + lane, kWave * 15 - 1)];
+                for (int it = 0; it < kCIters; ++it) cr[it] = s_c[min(it * kWave + lane, KC * 15 - 1)];
 #pragma unroll
-                for (int it = 0; it < 15; ++it) {
+                for (int it = 0; it < kCIters; ++it) {
                     const int i = it * kWave + lane;
                     if (i < np) dst[i] = cr[it];
                 }
             }
+        }
+
+        QLN_STAMP(2);
+        // ============================== Jacobian phase (jac_c!) ================================
+        if (WITH_J) {
+            // nothing of the value phase is kept: x, u are re-read from the staged slice, so the two
+            // phases' register sets do not add up (a spill reload would cost a vmcnt(0) drain)
             wave_lds_sync();
-        }
-        if (WITH_J) {
-            // structural zeros of the tile: written here, never touched by the value writes below
-            const double2 zero2 = make_double2(0.0, 0.0);
+            double x[14], F1x, F1y, F2x, F2y, h, th_next;
 #pragma unroll
-            for (int it = 0; it < (T * kBlk / 2 + kWave - 1) / kWave; ++it) {
-                const int i = it * kWave + lane;
-                if (i < T * kBlk / 2) s_j2[i] = zero2;
+            for (int i = 0; i < 14; ++i) x[i] = zl[i];
+            F1x = zl[15];
+            F1y = zl[16];
+            F2x = zl[17];
+            F2y = zl[18];
+            h = zl[19];
+            th_next = zl[22];
+            wave_lds_sync();
+            {
+                // structural zeros of the tile: written here, never touched by the value writes below
+                const double2 zero2 = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int it = 0; it < (T * kBlk / 2 + kWave - 1) / kWave; ++it) {
+                    const int i = it * kWave + lane;
+                    if (i < T * kBlk / 2) s_j2[i] = zero2;
+                }
             }
-        }
-
-        // keep the Jacobian arithmetic from being hoisted into the RK4 phase (register pressure)
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- the 85 non-zeros of the step block, closed form (see header) ---------------------
-        double jv[85];
-        if (WITH_J) {
             // clearance d/dtheta (src/constraints.jl:269-273; theta == 0 takes the + branch)
             if (valid) {
                 double* Vt = Vb + kBlk * (N - 1);
                 Vt[k] = (x[2] > 0) ? (-lb / 2 * cos(x[2])) : (lb / 2 * cos(x[2]));
-                if (k == N - 2) Vt[k + 1] = (xnext[2] > 0) ? (-lb / 2 * cos(xnext[2])) : (lb / 2 * cos(xnext[2]));
+                if (k == N - 2) Vt[k + 1] = (th_next > 0) ? (-lb / 2 * cos(th_next)) : (lb / 2 * cos(th_next));
             }
+
+            // ---- base quantities of the step block's 85 non-zeros (closed form, see header) ----
             const double m1 = f1free ? 1.0 : 0.0, m2 = f2free ? 1.0 : 0.0;
             const double keep = jump ? 0.0 : 1.0;  // jump*_jacobian() rows 5,7,11..15 (slot 15 too: quirk Q1)
+            const double km1 = keep * m1, km2 = keep * m2;
+            const double abx = (F1x + F2x) / mb, aby = (F1y + F2y) / mb + g;
+            const double a1x = m1 * (-F1x / mf), a1y = m1 * (-F1y / mf + g);
+            const double a2x = m2 * (-F2x / mf), a2y = m2 * (-F2y / mf + g);
             const double h2 = h * h, h3 = h2 * h, h4 = h2 * h2;
             const double iIb = 1.0 / Ib;
-            const double Aw = h * iIb;                // omega row: weight of tau0
-            const double At = 0.5 * h2 * iIb;         // theta row: tau0;  omega row: tauv
-            const double Bt = h3 * iIb * (1.0 / 6.0); // theta row: tauv;  omega row: taua
+            const double Aw = h * iIb;                 // omega row: weight of tau0
+            const double At = 0.5 * h2 * iIb;          // theta row: tau0;  omega row: tauv
+            const double Bt = h3 * iIb * (1.0 / 6.0);  // theta row: tauv;  omega row: taua
             const double Ct = h4 * iIb * (1.0 / 24.0);
             const double sFx = F1x + F2x, sFy = F1y + F2y;
             const double r1x = x[3] - x[0], r1y = x[4] - x[1], r2x = x[5] - x[0], r2y = x[6] - x[1];
@@ -303,178 +338,127 @@ __global__ __launch_bounds__(kWave, 2) void k_constraint_jacobian(BatchParams P,
             const double tauv = w1x * F1y - w1y * F1x + w2x * F2y - w2y * F2x;
             const double ga1 = g * (1.0 - m1), ga2 = g * (1.0 - m2);
             const double taua = ga1 * F1x + ga2 * F2x;
-            const double hmb = h / mb, h2mb = 0.5 * h2 / mb;
-            const double hmf = h / mf, h2mf = 0.5 * h2 / mf;
-            int n = 0;
-            // row 0 (xb): cols 0,7,15,17,19
-            jv[n++] = 1.0;
-            jv[n++] = h;
-            jv[n++] = h2mb;
-            jv[n++] = h2mb;
-            jv[n++] = x[7] + h * sc.abx;
-            // row 1 (yb): cols 1,8,16,18,19
-            jv[n++] = 1.0;
-            jv[n++] = h;
-            jv[n++] = h2mb;
-            jv[n++] = h2mb;
-            jv[n++] = x[8] + h * sc.aby;
-            // row 2 (theta): cols 0..13, 15..19
-            jv[n++] = -At * sFy;
-            jv[n++] = At * sFx;
-            jv[n++] = 1.0;
-            jv[n++] = At * F1y;
-            jv[n++] = -At * F1x;
-            jv[n++] = At * F2y;
-            jv[n++] = -At * F2x;
-            jv[n++] = -Bt * sFy;
-            jv[n++] = Bt * sFx;
-            jv[n++] = h;
-            jv[n++] = Bt * m1 * F1y;
-            jv[n++] = -Bt * m1 * F1x;
-            jv[n++] = Bt * m2 * F2y;
-            jv[n++] = -Bt * m2 * F2x;
-            jv[n++] = -At * r1y - Bt * w1y + Ct * ga1;
-            jv[n++] = At * r1x + Bt * w1x;
-            jv[n++] = -At * r2y - Bt * w2y + Ct * ga2;
-            jv[n++] = At * r2x + Bt * w2x;
-            jv[n++] = x[9] + (Aw * tau0 + At * tauv + Bt * taua);
-            // row 3 (x1): cols 3,10,15,19      row 4 (y1): cols 4,11,16,19 (masked at the jump)
-            jv[n++] = 1.0;
-            jv[n++] = m1 * h;
-            jv[n++] = -m1 * h2mf;
-            jv[n++] = m1 * (x[10] + h * sc.a1x);
-            jv[n++] = keep;
-            jv[n++] = keep * m1 * h;
-            jv[n++] = -keep * m1 * h2mf;
-            jv[n++] = keep * m1 * (x[11] + h * sc.a1y);
-            // row 5 (x2): cols 5,12,17,19      row 6 (y2): cols 6,13,18,19 (masked)
-            jv[n++] = 1.0;
-            jv[n++] = m2 * h;
-            jv[n++] = -m2 * h2mf;
-            jv[n++] = m2 * (x[12] + h * sc.a2x);
-            jv[n++] = keep;
-            jv[n++] = keep * m2 * h;
-            jv[n++] = -keep * m2 * h2mf;
-            jv[n++] = keep * m2 * (x[13] + h * sc.a2y);
-            // row 7 (vbx): cols 7,15,17,19     row 8 (vby): cols 8,16,18,19
-            jv[n++] = 1.0;
-            jv[n++] = hmb;
-            jv[n++] = hmb;
-            jv[n++] = sc.abx;
-            jv[n++] = 1.0;
-            jv[n++] = hmb;
-            jv[n++] = hmb;
-            jv[n++] = sc.aby;
-            // row 9 (omega): cols 0,1,3..13,15..19
-            jv[n++] = -Aw * sFy;
-            jv[n++] = Aw * sFx;
-            jv[n++] = Aw * F1y;
-            jv[n++] = -Aw * F1x;
-            jv[n++] = Aw * F2y;
-            jv[n++] = -Aw * F2x;
-            jv[n++] = -At * sFy;
-            jv[n++] = At * sFx;
-            jv[n++] = 1.0;
-            jv[n++] = At * m1 * F1y;
-            jv[n++] = -At * m1 * F1x;
-            jv[n++] = At * m2 * F2y;
-            jv[n++] = -At * m2 * F2x;
-            jv[n++] = -Aw * r1y - At * w1y + Bt * ga1;
-            jv[n++] = Aw * r1x + At * w1x;
-            jv[n++] = -Aw * r2y - At * w2y + Bt * ga2;
-            jv[n++] = Aw * r2x + At * w2x;
-            jv[n++] = iIb * (tau0 + h * tauv + 0.5 * h2 * taua);
-            // rows 10..13 (foot velocities; masked at the jump): diag, own force, h
-            jv[n++] = keep;
-            jv[n++] = -keep * m1 * hmf;
-            jv[n++] = keep * sc.a1x;
-            jv[n++] = keep;
-            jv[n++] = -keep * m1 * hmf;
-            jv[n++] = keep * sc.a1y;
-            jv[n++] = keep;
-            jv[n++] = -keep * m2 * hmf;
-            jv[n++] = keep * sc.a2x;
-            jv[n++] = keep;
-            jv[n++] = -keep * m2 * hmf;
-            jv[n++] = keep * sc.a2y;
-            // row 14 (clock; masked at the jump -- quirk Q1): cols 14,19
-            jv[n++] = keep;
-            jv[n++] = keep;
-        }
+            const double hmb = h / mb, h2mb = 0.5 * h2 / mb, hmf = h / mf, h2mf = 0.5 * h2 / mf;
 
-        // ---- assemble T knots at a time in LDS and stream them out ----------------------------
-        const int nt = (nk + T - 1) / T;
-        for (int t = 0; t < nt; ++t) {
-            const int kb = kc0 + t * T;           // first knot of the sub-tile
-            const int nkt = min(T, nk - t * T);   // knots in it
-            if (valid && (lane / T) == t) {
-                const int r = lane - t * T;
-                if (WITH_J) {
-                    double* jr = s_j + r * kBlk;
-#define JW(row, col, idx) jr[(row) + 15 * (col)] = jv[idx]
-                    JW(0, 0, 0); JW(0, 7, 1); JW(0, 15, 2); JW(0, 17, 3); JW(0, 19, 4);
-                    JW(1, 1, 5); JW(1, 8, 6); JW(1, 16, 7); JW(1, 18, 8); JW(1, 19, 9);
-                    JW(2, 0, 10); JW(2, 1, 11); JW(2, 2, 12); JW(2, 3, 13); JW(2, 4, 14); JW(2, 5, 15); JW(2, 6, 16);
-                    JW(2, 7, 17); JW(2, 8, 18); JW(2, 9, 19); JW(2, 10, 20); JW(2, 11, 21); JW(2, 12, 22); JW(2, 13, 23);
-                    JW(2, 15, 24); JW(2, 16, 25); JW(2, 17, 26); JW(2, 18, 27); JW(2, 19, 28);
-                    JW(3, 3, 29); JW(3, 10, 30); JW(3, 15, 31); JW(3, 19, 32);
-                    JW(4, 4, 33); JW(4, 11, 34); JW(4, 16, 35); JW(4, 19, 36);
-                    JW(5, 5, 37); JW(5, 12, 38); JW(5, 17, 39); JW(5, 19, 40);
-                    JW(6, 6, 41); JW(6, 13, 42); JW(6, 18, 43); JW(6, 19, 44);
-                    JW(7, 7, 45); JW(7, 15, 46); JW(7, 17, 47); JW(7, 19, 48);
-                    JW(8, 8, 49); JW(8, 16, 50); JW(8, 18, 51); JW(8, 19, 52);
-                    JW(9, 0, 53); JW(9, 1, 54); JW(9, 3, 55); JW(9, 4, 56); JW(9, 5, 57); JW(9, 6, 58); JW(9, 7, 59);
-                    JW(9, 8, 60); JW(9, 9, 61); JW(9, 10, 62); JW(9, 11, 63); JW(9, 12, 64); JW(9, 13, 65);
-                    JW(9, 15, 66); JW(9, 16, 67); JW(9, 17, 68); JW(9, 18, 69); JW(9, 19, 70);
-                    JW(10, 10, 71); JW(10, 15, 72); JW(10, 19, 73);
-                    JW(11, 11, 74); JW(11, 16, 75); JW(11, 19, 76);
-                    JW(12, 12, 77); JW(12, 17, 78); JW(12, 19, 79);
-                    JW(13, 13, 80); JW(13, 18, 81); JW(13, 19, 82);
-                    JW(14, 14, 83); JW(14, 19, 84);
+            // Values kept live across the sub-tile loop: column 19 (dense), the eight force-column
+            // entries of the theta/omega rows and a dozen scalars.  The 30 (weight x force) products
+            // of the theta/omega rows are formed at write time from At/Bt/Aw (one multiply each):
+            // keeping all 85 entries in VGPRs across the loop is what used to force scratch spills,
+            // and a spill reload is an in-order vmcnt(0) wait that drains the store stream.
+            double hc[15];
+            hc[0] = x[7] + h * abx;
+            hc[1] = x[8] + h * aby;
+            hc[2] = x[9] + (Aw * tau0 + At * tauv + Bt * taua);
+            hc[3] = m1 * (x[10] + h * a1x);
+            hc[4] = km1 * (x[11] + h * a1y);
+            hc[5] = m2 * (x[12] + h * a2x);
+            hc[6] = km2 * (x[13] + h * a2y);
+            hc[7] = abx;
+            hc[8] = aby;
+            hc[9] = iIb * (tau0 + h * tauv + 0.5 * h2 * taua);
+            hc[10] = keep * a1x;
+            hc[11] = keep * a1y;
+            hc[12] = keep * a2x;
+            hc[13] = keep * a2y;
+            hc[14] = keep;
+            const double t15 = -At * r1y - Bt * w1y + Ct * ga1, t16 = At * r1x + Bt * w1x;
+            const double t17 = -At * r2y - Bt * w2y + Ct * ga2, t18 = At * r2x + Bt * w2x;
+            const double o15 = -Aw * r1y - At * w1y + Bt * ga1, o16 = Aw * r1x + At * w1x;
+            const double o17 = -Aw * r2y - At * w2y + Bt * ga2, o18 = Aw * r2x + At * w2x;
+            const double mF1x = m1 * F1x, mF1y = m1 * F1y, mF2x = m2 * F2x, mF2y = m2 * F2y;
+            const double s_m1h = m1 * h, s_m1h2 = -m1 * h2mf, s_k1h = km1 * h, s_k1h2 = -km1 * h2mf;
+            const double s_m2h = m2 * h, s_m2h2 = -m2 * h2mf, s_k2h = km2 * h, s_k2h2 = -km2 * h2mf;
+            const double s_k1f = -km1 * hmf, s_k2f = -km2 * hmf;
+            double wAt = At, wBt = Bt, wAw = Aw;
+
+            QLN_STAMP(3);
+            // ---- assemble T knots at a time in LDS and stream them out ---------------------------
+            const int nt = (nk + T - 1) / T;
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) {
+                const int kb = kc0 + t * T;          // first knot of the sub-tile
+                const int nkt = min(T, nk - t * T);  // knots in it
+                if (valid && (lane / T) == t) {
+                    double* jr = s_j + (lane - t * T) * kBlk;
+#define JW(row, col, val) jr[(row) + 15 * (col)] = (val)
+                    // opaque to loop-invariant code motion (see above)
+                    asm volatile("" : "+v"(wAt), "+v"(wBt), "+v"(wAw));
+#pragma unroll
+                    for (int r15 = 0; r15 < 15; ++r15) JW(r15, 19, hc[r15]);
+                    // row 2 (theta): cols 0..13, 15..18
+                    JW(2, 0, -wAt * sFy); JW(2, 1, wAt * sFx); JW(2, 2, 1.0);
+                    JW(2, 3, wAt * F1y); JW(2, 4, -wAt * F1x); JW(2, 5, wAt * F2y); JW(2, 6, -wAt * F2x);
+                    JW(2, 7, -wBt * sFy); JW(2, 8, wBt * sFx); JW(2, 9, h);
+                    JW(2, 10, wBt * mF1y); JW(2, 11, -wBt * mF1x); JW(2, 12, wBt * mF2y); JW(2, 13, -wBt * mF2x);
+                    JW(2, 15, t15); JW(2, 16, t16); JW(2, 17, t17); JW(2, 18, t18);
+                    // row 9 (omega): cols 0,1,3..13,15..18
+                    JW(9, 0, -wAw * sFy); JW(9, 1, wAw * sFx);
+                    JW(9, 3, wAw * F1y); JW(9, 4, -wAw * F1x); JW(9, 5, wAw * F2y); JW(9, 6, -wAw * F2x);
+                    JW(9, 7, -wAt * sFy); JW(9, 8, wAt * sFx); JW(9, 9, 1.0);
+                    JW(9, 10, wAt * mF1y); JW(9, 11, -wAt * mF1x); JW(9, 12, wAt * mF2y); JW(9, 13, -wAt * mF2x);
+                    JW(9, 15, o15); JW(9, 16, o16); JW(9, 17, o17); JW(9, 18, o18);
+                    // rows 0, 1 (body position)
+                    JW(0, 0, 1.0); JW(0, 7, h); JW(0, 15, h2mb); JW(0, 17, h2mb);
+                    JW(1, 1, 1.0); JW(1, 8, h); JW(1, 16, h2mb); JW(1, 18, h2mb);
+                    // rows 3..6 (foot positions; the y rows are masked at the jump)
+                    JW(3, 3, 1.0); JW(3, 10, s_m1h); JW(3, 15, s_m1h2);
+                    JW(4, 4, keep); JW(4, 11, s_k1h); JW(4, 16, s_k1h2);
+                    JW(5, 5, 1.0); JW(5, 12, s_m2h); JW(5, 17, s_m2h2);
+                    JW(6, 6, keep); JW(6, 13, s_k2h); JW(6, 18, s_k2h2);
+                    // rows 7, 8 (body velocity)
+                    JW(7, 7, 1.0); JW(7, 15, hmb); JW(7, 17, hmb);
+                    JW(8, 8, 1.0); JW(8, 16, hmb); JW(8, 18, hmb);
+                    // rows 10..13 (foot velocities), row 14 (clock): masked at the jump (quirk Q1)
+                    JW(10, 10, keep); JW(10, 15, s_k1f);
+                    JW(11, 11, keep); JW(11, 16, s_k1f);
+                    JW(12, 12, keep); JW(12, 17, s_k2f);
+                    JW(13, 13, keep); JW(13, 18, s_k2f);
+                    JW(14, 14, keep);
 #undef JW
                 }
-            }
-            wave_lds_sync();
-            if (WITH_J) {
-                // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
-                double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
-                const int np = nkt * (kBlk / 2);
-                constexpr int kPieces = T * kBlk / 2;              // 16-byte pieces in a full tile
-                constexpr int kFull = kPieces / kWave;             // unpredicated wave instructions
-                constexpr int kGroup = 6;                          // LDS reads in flight per batch
-                if (nkt == T) {
-                    // full tile: batches of kGroup ds_read_b128 then kGroup 1-KiB stores
+                wave_lds_sync();
+                {
+                    // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
+                    double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
+                    const int np = nkt * (kBlk / 2);
+                    constexpr int kPieces = T * kBlk / 2;   // 16-byte pieces in a full tile
+                    constexpr int kFull = kPieces / kWave;  // unpredicated wave instructions
+                    constexpr int kGroup = 6;               // LDS reads in flight per batch
+                    if (nkt == T) {
 #pragma unroll
-                    for (int g0 = 0; g0 < kFull; g0 += kGroup) {
-                        double2 r[kGroup];
+                        for (int g0 = 0; g0 < kFull; g0 += kGroup) {
+                            double2 r[kGroup];
 #pragma unroll
-                        for (int j = 0; j < kGroup; ++j)
-                            if (g0 + j < kFull) r[j] = s_j2[(g0 + j) * kWave + lane];
+                            for (int j = 0; j < kGroup; ++j)
+                                if (g0 + j < kFull) r[j] = s_j2[(g0 + j) * kWave + lane];
 #pragma unroll
-                        for (int j = 0; j < kGroup; ++j)
-                            if (g0 + j < kFull) dst[(g0 + j) * kWave + lane] = r[j];
-                    }
-                    if (kPieces % kWave) {
-                        const int i = kFull * kWave + lane;
-                        if (i < kPieces) dst[i] = s_j2[i];
-                    }
-                } else {
+                            for (int j = 0; j < kGroup; ++j)
+                                if (g0 + j < kFull) dst[(g0 + j) * kWave + lane] = r[j];
+                        }
+                        if (kPieces % kWave) {
+                            const int i = kFull * kWave + lane;
+                            if (i < kPieces) dst[i] = s_j2[i];
+                        }
+                    } else {
 #pragma unroll 1
-                    for (int g0 = 0; g0 * kWave < np; g0 += kGroup) {
-                        double2 r[kGroup];
+                        for (int g0 = 0; g0 * kWave < np; g0 += kGroup) {
+                            double2 r[kGroup];
 #pragma unroll
-                        for (int j = 0; j < kGroup; ++j) r[j] = s_j2[min((g0 + j) * kWave + lane, kPieces - 1)];
+                            for (int j = 0; j < kGroup; ++j) r[j] = s_j2[min((g0 + j) * kWave + lane, kPieces - 1)];
 #pragma unroll
-                        for (int j = 0; j < kGroup; ++j) {
-                            const int i = (g0 + j) * kWave + lane;
-                            if (i < np) dst[i] = r[j];
+                            for (int j = 0; j < kGroup; ++j) {
+                                const int i = (g0 + j) * kWave + lane;
+                                if (i < np) dst[i] = r[j];
+                            }
                         }
                     }
                 }
+                wave_lds_sync();
+                QLN_STAMP(4 + min(t, 10));
             }
-            wave_lds_sync();
         }
     }
+    QLN_STAMP(15);
 }
 
 // constants only (qln_jacobian_init_constants)
@@ -572,25 +556,42 @@ __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const
     Gb[i] = (k < N - 1) ? Zb[20 * k + 19] * lin : lin;
 }
 
-template <int T>
+template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
     dim3 grid(nb), block(kWave);
     if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, true, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
     else if (c)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, true, false>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
     else
-        hipLaunchKernelGGL((k_constraint_jacobian<T, false, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
     return hipGetLastError();
 }
 
 }  // namespace
 
+#ifdef QLN_DIAG
+extern "C" int qln_diag_set_stamps(void* dev_ptr) {
+    unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(qln::g_stamps), &p, sizeof(p));
+}
+#endif
+
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
                                       double* vals, uint32_t flags, hipStream_t stream) {
     if (nb <= 0 || (!c && !vals)) return hipSuccess;
-    return launch_cj_t<8>(p, b_begin, nb, Z, c, vals, flags, stream);
+    // tuning knob for experiments (QLN_VARIANT env var is read once); the default is what ships
+    static const int variant = [] {
+        const char* e = getenv("QLN_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    switch (variant) {
+        case 1: return launch_cj_t<5, 40, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 2: return launch_cj_t<4, 32, 4>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 3: return launch_cj_t<6, 48, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
+        default: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+    }
 }
 
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream) {
