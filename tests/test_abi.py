@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/qln_evaluator.h declares, and
+fails loudly (no CPU fallback) when asked to create a handle without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from quadruped_landing_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "qln_evaluator.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qln_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    for name in _declared():
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.qln_version()
+
+
+def test_struct_layouts_match_the_header():
+    # qln_model: 6 doubles; qln_batch_desc and qln_dims as declared (natural alignment)
+    assert C.sizeof(_lib.QlnModel) == 48
+    assert C.sizeof(_lib.QlnBatchDesc) == 8 + 48 + 5 * 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.QlnDims) == 6 * 4 + 4 * 8
+
+
+def test_argument_validation_needs_no_gpu():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.qln_create(None, 0, C.byref(h)) == _lib.QLN_ERR_INVALID_ARGUMENT
+    d = _lib.QlnBatchDesc()
+    d.B, d.N = 1, 1
+    assert L.qln_create(C.byref(d), 0, C.byref(h)) == _lib.QLN_ERR_INVALID_ARGUMENT
+    assert b"N must be >= 2" in L.qln_last_error()
+    assert L.qln_get_dims(None, None) == _lib.QLN_ERR_INVALID_ARGUMENT
+    assert L.qln_destroy(None) == _lib.QLN_OK
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import quadruped_landing_amd as Q
+    from quadruped_landing_amd import problem_gen as PG
+
+    b = PG.make_batch(2, 5, 3, 1)
+    with pytest.raises(_lib.QlnError) as ei:
+        Q.HybridNLP(b.model, b.obj, b.init_mode, b.k_trans, b.N, b.x0, b.xf)
+    assert ei.value.code in (_lib.QLN_ERR_NO_DEVICE, _lib.QLN_ERR_HIP)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "quadruped_landing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower(), f

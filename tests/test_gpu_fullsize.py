@@ -1,0 +1,118 @@
+"""BASELINE.json's full-size configurations on the GPU: size-independent properties plus a sampled
+comparison with the oracle (the oracle needs ~4 us per knot, so it checks a few hundred problems)."""
+import numpy as np
+import pytest
+
+from tests.helpers import oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def _setup(B, N, ragged, seed=0):
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(B, N, 14, 1, seed=seed, ragged=ragged)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                    stream=torch.cuda.current_stream())
+    return batch, nlp, nlp.upload_Z(batch.Z)
+
+
+def _oracle_sample(batch, idx):
+    from oracle import oracle as O
+
+    out = []
+    for b in idx:
+        obj = batch.obj if batch.obj.ndim == 2 else batch.obj[b]
+        o = O.OracleNLP(batch.N, int(batch.k_trans[b]), int(batch.init_mode[b]), batch.x0[b], batch.xf[b], obj,
+                        oracle_model(batch.model))
+        out.append((o.eval_c(batch.Z[b]), o.jac_c_coo(batch.Z[b]), o.eval_f(batch.Z[b]), o.grad_f(batch.Z[b])))
+    return out
+
+
+@pytest.mark.parametrize("B,N,ragged", [(65536, 40, False), (65536, 80, True)])
+def test_full_size_configs(B, N, ragged):
+    import torch
+
+    batch, nlp, Z = _setup(B, N, ragged)
+    nan = float("nan")
+    c = torch.full((nlp.dims.c_total,), nan, dtype=torch.float64, device="cuda")
+    v = torch.full((nlp.dims.j_total,), nan, dtype=torch.float64, device="cuda")
+    nlp.eval_c_and_jac(Z, c, v, write_constants=True)
+    f, g = nlp.eval_f(Z), nlp.grad_f(Z)
+    torch.cuda.synchronize()
+
+    # 1. every slot of every problem is written, padding is untouched
+    m = np.array([18 * N - k + 16 for k in batch.k_trans])
+    nz = np.array([300 * (N - 1) + N + 435 + 15 * (N - 1) + 3 * N - k + 3 for k in batch.k_trans])
+    assert int(torch.isnan(c).sum()) == nlp.dims.c_total - int(m.sum())
+    assert int(torch.isnan(v).sum()) == nlp.dims.j_total - int(nz.sum())
+
+    # 2. sampled comparison with the oracle, incl. the first and last problem
+    rng = np.random.default_rng(1)
+    idx = np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, size=126)]))
+    ch, vh, fh, gh = c.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    worst = 0.0
+    for b, (oc, ov, of, og) in zip(idx, _oracle_sample(batch, idx)):
+        gc, gv = nlp.split_c(ch, b), nlp.split_vals(vh, b)
+        assert np.array_equal(gv == 0, ov == 0)  # sparsity bit-exact
+        worst = max(worst, rel_err(gc, oc, floor=1.0), rel_err(gv, ov, floor=1e-300), abs(fh[b] - of) / abs(of),
+                    rel_err(gh[b * nlp.z_stride : b * nlp.z_stride + nlp.n_nlp], og, floor=1e-300))
+    print(f"B={B} N={N}: worst rel err over {len(idx)} sampled problems = {worst:.3e}")
+    assert worst <= RTOL
+
+    # 3. idempotence and fused == separate entry points (bitwise)
+    c2, v2 = nlp.eval_c(Z), nlp.jac_c(Z, write_constants=True)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(c, nan=0.0), c2)
+    assert torch.equal(torch.nan_to_num(v, nan=0.0), v2)
+    del c2, v2
+
+    # 4. the step blocks are the derivative of the dynamics rows: J*d vs central differences of c,
+    #    over the whole batch, on the GPU (uniform layout only)
+    if not ragged:
+        nb = 4096
+        eps = 1e-6
+        d = torch.randn(B, nlp.z_stride, dtype=torch.float64, device="cuda")
+        d[:, nlp.n_nlp:] = 0
+        d[:, 19::20] *= 1e-3  # keep h positive
+        cp = nlp.eval_c((Z.view(B, -1) + eps * d).reshape(-1).contiguous())
+        cm = nlp.eval_c((Z.view(B, -1) - eps * d).reshape(-1).contiguous())
+        stride_c = nlp.c_off[1] - nlp.c_off[0]
+        fd = ((cp - cm) / (2 * eps)).view(B, stride_c)[:nb, 29 : 29 + 15 * (N - 1)].reshape(nb, N - 1, 15)
+        stride_j = nlp.j_off[1] - nlp.j_off[0]
+        blocks = v.view(B, stride_j)[:nb, : 300 * (N - 1)].reshape(nb, N - 1, 20, 15)  # column-major 15x20
+        dz = d[:nb, : 20 * (N - 1)].reshape(nb, N - 1, 20)
+        nxt = (20 * (torch.arange(N - 1, device="cuda") + 1))[:, None] + torch.arange(15, device="cuda")[None, :]
+        dxn = d[:nb][:, nxt]  # perturbation of x_{k+1}: (nb, N-1, 15)
+        jd = torch.einsum("bkcr,bkc->bkr", blocks, dz) - dxn
+        # quirk Q1: the reference zeroes the clock row of the jump knot's block; exclude that one entry
+        kj = int(batch.k_trans[0]) - 2
+        err = (jd - fd).abs()
+        err[:, kj, 14] = 0
+        assert float(err.max()) <= 1e-5 * max(1.0, float(fd.abs().max()))
+
+
+def test_permutation_equivariance():
+    """Problems are independent: evaluating a permuted batch permutes the outputs, bit for bit."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(4096, 40, seed=2, ragged=True)
+    perm = np.random.default_rng(0).permutation(batch.B)
+
+    def run(ix):
+        nlp = HybridNLP(batch.model, batch.obj[ix], batch.init_mode[ix], batch.k_trans[ix], batch.N, batch.x0[ix], batch.xf[ix])
+        Z = nlp.upload_Z(batch.Z[ix])
+        c, v = nlp.eval_c_and_jac(Z)
+        f = nlp.eval_f(Z)
+        torch.cuda.synchronize()
+        return nlp, c.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy()
+
+    n0, c0, v0, f0 = run(np.arange(batch.B))
+    n1, c1, v1, f1 = run(perm)
+    assert np.array_equal(f1, f0[perm])
+    for i in (0, 1, 17, 4095):
+        assert np.array_equal(n1.split_c(c1, i), n0.split_c(c0, perm[i]))
+        assert np.array_equal(n1.split_vals(v1, i), n0.split_vals(v0, perm[i]))

@@ -1,0 +1,83 @@
+"""Host side of the boundary (no GPU): index maps, bounds, packZ/unpackZ, cost/reference-trajectory setup
+and the synthetic generator, each against the oracle's restatement of the same reference code."""
+import numpy as np
+import pytest
+
+import quadruped_landing_amd as Q
+from quadruped_landing_amd import nlp as NLP
+from quadruped_landing_amd import problem_gen as PG
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("N,kt", [(61, 21), (40, 14), (2, 2), (80, 79), (80, 2), (12, 13), (12, 1)])
+def test_index_maps_match_oracle(N, kt):
+    o = O.OracleNLP(N, kt, 1, np.zeros(15), np.zeros(15), np.zeros((N, 41)))
+    assert NLP.num_primals(N) == o.n_nlp == 20 * N - 5
+    assert NLP.num_duals(N, kt) == o.m_nlp == 18 * N - kt + 16
+    assert NLP.cinds(N, kt) == o.cinds()
+    lb, ub = NLP.constraint_bounds(N, kt)
+    lo, uo = o.bounds()
+    assert np.array_equal(lb, lo) and np.array_equal(ub, uo)
+
+
+def test_xinds_uinds_are_the_references():
+    # src/nlp.jl:38-39: xinds[k] = (k-1)*20 + (1:15), uinds[k] = (k-1)*20 + (16:20)
+    xi, ui = NLP.xinds(61), NLP.uinds(61)
+    assert len(xi) == 61 and len(ui) == 60
+    assert xi[0].tolist() == list(range(1, 16)) and ui[0].tolist() == list(range(16, 21))
+    assert xi[60].tolist() == list(range(1201, 1216)) and ui[59][-1] == 1200
+
+
+def test_pack_unpack_roundtrip():
+    rng = np.random.default_rng(0)
+    X, U = rng.normal(size=(3, 7, 15)), rng.normal(size=(3, 6, 5))
+    Z = NLP.packZ(7, X, U)
+    assert Z.shape == (3, 135)
+    X2, U2 = NLP.unpackZ(7, Z)
+    assert np.array_equal(X, X2) and np.array_equal(U, U2)
+    assert np.array_equal(Z[1, 20:35], X[1, 1]) and np.array_equal(Z[1, 35:40], U[1, 1])
+
+
+@pytest.mark.parametrize("init_mode", [1, 2])
+def test_reference_trajectory_and_lqr_cost_bitwise(init_mode):
+    model = Q.PlanarQuadruped()
+    xterm = PG.terminal_state(model)
+    Xr, Ur = Q.reference_trajectory(model, 61, 21, xterm, init_mode, 0.009)
+    Xo, Uo = O.reference_trajectory(61, 21, xterm, init_mode, 0.009)
+    assert np.array_equal(Ur, Uo)
+    assert np.array_equal(Xr[:, :14], Xo[:, :14]) and np.max(np.abs(Xr[:, 14] - Xo[:, 14])) <= 1e-15
+    tab = Q.lqr_objective(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, Xr, Ur)
+    assert np.array_equal(tab, O.lqr_cost_table(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, Xo, Uo))
+    assert Ur[0, 1 if init_mode == 1 else 3] == 98.10000000000001
+
+
+def test_notebook_problem_matches_oracle_setup():
+    nb = PG.notebook_problem()
+    nlp, xinit, xterm, Xref, Uref = O.notebook_problem()
+    assert np.array_equal(nb.x0[0], xinit) and np.array_equal(nb.xf[0], xterm)
+    assert np.array_equal(nb.obj, nlp.cost)
+    assert np.array_equal(nb.Z[0], O.notebook_initial_guess(61, 21, xinit, xterm, Uref))
+
+
+def test_generator_is_deterministic_and_in_range():
+    a = PG.make_batch(64, 40, 14, 1, seed=0)
+    b = PG.make_batch(64, 40, 14, 1, seed=0)
+    assert np.array_equal(a.Z, b.Z) and np.array_equal(a.x0, b.x0)
+    assert not np.array_equal(a.Z, PG.make_batch(64, 40, 14, 1, seed=1).Z)
+    h = a.Z[:, 19::20]
+    assert h.shape == (64, 39) and h.min() >= 0.001 and h.max() <= 0.02
+    th = np.rad2deg(a.x0[:, 2])
+    assert th.min() >= -40 and th.max() <= -10
+    r = PG.make_batch(256, 80, seed=3, ragged=True)
+    assert r.k_trans.min() >= 2 and r.k_trans.max() <= 79 and set(np.unique(r.init_mode)) == {1, 2}
+    assert r.obj.shape == (256, 80, 41)
+
+
+def test_moi_surface_names():
+    from quadruped_landing_amd import moi
+
+    # the seven MOI methods of src/moi.jl:1-33
+    for name in ("eval_objective", "eval_objective_gradient", "eval_constraint", "eval_constraint_jacobian",
+                 "features_available", "initialize", "jacobian_structure"):
+        assert callable(getattr(moi, name))
+    assert moi.features_available(None) == ["Grad", "Jac"] and moi.initialize(None, ["Grad"]) is None
