@@ -1,0 +1,83 @@
+# HybridNLPHIP.jl -- the reference-side binding: a drop-in MOI.AbstractNLPEvaluator that forwards the
+# callbacks of /root/reference/src/moi.jl:1-33 to libqln_hip.so (C ABI: include/qln_evaluator.h).
+#
+# NOT EXECUTED in this pipeline (no Julia on either box) -- kept free of logic so that review by
+# reading is credible: every method is one ccall.  Usage inside the reference's notebook, after
+# `include("nlp.jl")` etc.:   nlp = HybridNLPHIP(model, obj, init_mode, k_trans, N, xinit, xterm)
+#                              Z_sol, solver = solve(Z0, nlp)            # src/moi.jl:46, unchanged
+using MathOptInterface
+const MOI = MathOptInterface
+const LIBQLN = get(ENV, "QLN_LIB", joinpath(@__DIR__, "..", "..", "quadruped_landing_amd", "csrc", "libqln_hip.so"))
+
+struct QlnModel; g::Cdouble; mb::Cdouble; mf::Cdouble; lb::Cdouble; l1::Cdouble; l2::Cdouble; end
+struct QlnBatchDesc
+    B::Int32; N::Int32; model::QlnModel
+    k_trans::Ptr{Int32}; init_mode::Ptr{Int32}; x0::Ptr{Cdouble}; xf::Ptr{Cdouble}; cost::Ptr{Cdouble}
+    cost_batch::Int32; z_stride::Int64; align::Int32
+end
+
+qln_check(rc) = rc == 0 || error("libqln_hip: " * unsafe_string(ccall((:qln_last_error, LIBQLN), Cstring, ())))
+
+mutable struct HybridNLPHIP <: MOI.AbstractNLPEvaluator
+    handle::Ptr{Cvoid}
+    N::Int; k_trans::Int; init_mode::Int
+    lb::Vector{Float64}; ub::Vector{Float64}      # fields solve() reads (src/moi.jl:69)
+    n_nlp::Int; m_nlp::Int
+    use_sparse_jacobian::Bool
+end
+
+# HybridNLP(model, obj, init_mode, k_trans, N, x0, xf) -- src/nlp.jl:34-37.  `obj` is the reference's
+# Vector{QuadraticCost}; it is flattened to the 41-double records [Q(15) R(5) q(15) r(5) c].
+function HybridNLPHIP(model, obj, init_mode, k_trans, N, x0, xf; use_sparse_jacobian=false, device=0)
+    cost = vcat([[diag(o.Q); diag(o.R); o.q; o.r; o.c] for o in obj]...)
+    kt = Int32[k_trans]; im = Int32[init_mode]; x0v = collect(Float64, x0); xfv = collect(Float64, xf)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve cost kt im x0v xfv begin
+        d = Ref(QlnBatchDesc(1, N, QlnModel(model.g, model.mb, model.mf, model.lb, model.l1, model.l2),
+                             pointer(kt), pointer(im), pointer(x0v), pointer(xfv), pointer(cost), 1, 0, 0))
+        qln_check(ccall((:qln_create, LIBQLN), Cint, (Ref{QlnBatchDesc}, Cint, Ref{Ptr{Cvoid}}), d, device, h))
+    end
+    m = Ref{Int32}(0); nnz = Ref{Int32}(0)
+    qln_check(ccall((:qln_problem_dims, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ref{Int32}, Ref{Int32}), h[], 0, m, nnz))
+    lb = zeros(m[]); ub = zeros(m[])
+    qln_check(ccall((:qln_constraint_bounds, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Cdouble}), h[], 0, lb, ub))
+    nlp = HybridNLPHIP(h[], N, k_trans, init_mode, lb, ub, 20N - 5, m[], use_sparse_jacobian)
+    finalizer(p -> ccall((:qln_destroy, LIBQLN), Cint, (Ptr{Cvoid},), p.handle), nlp)
+end
+
+num_primals(nlp::HybridNLPHIP) = nlp.n_nlp      # src/nlp.jl:86
+num_duals(nlp::HybridNLPHIP) = nlp.m_nlp        # src/nlp.jl:87
+
+function MOI.eval_objective(prob::HybridNLPHIP, x)                      # src/moi.jl:1-3
+    f = Ref{Cdouble}(0.0)
+    qln_check(ccall((:qln_eval_objective_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{Cdouble}), prob.handle, x, f))
+    return f[]
+end
+function MOI.eval_objective_gradient(prob::HybridNLPHIP, grad_f, x)     # src/moi.jl:5-8
+    qln_check(ccall((:qln_eval_objective_gradient_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), prob.handle, x, grad_f))
+    return nothing
+end
+function MOI.eval_constraint(prob::HybridNLPHIP, g, x)                  # src/moi.jl:10-13
+    qln_check(ccall((:qln_eval_constraint_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), prob.handle, x, g))
+    return nothing
+end
+function MOI.eval_constraint_jacobian(prob::HybridNLPHIP, vec, x)       # src/moi.jl:15-24
+    if prob.use_sparse_jacobian   # vec has one slot per entry of jacobian_structure (block-COO order)
+        qln_check(ccall((:qln_eval_constraint_jacobian_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), prob.handle, x, vec))
+    else                          # dense column-major m_nlp x n_nlp; only jac_c!'s write-set is assigned
+        qln_check(ccall((:qln_eval_constraint_jacobian_dense_host, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Cdouble}), prob.handle, 0, x, vec))
+    end
+    return nothing
+end
+MOI.features_available(prob::HybridNLPHIP) = [:Grad, :Jac]              # src/moi.jl:26-28
+MOI.initialize(prob::HybridNLPHIP, features) = nothing                  # src/moi.jl:30
+function MOI.jacobian_structure(nlp::HybridNLPHIP)                      # src/moi.jl:31-33
+    if !nlp.use_sparse_jacobian
+        return vec(Tuple.(CartesianIndices(zeros(num_duals(nlp), num_primals(nlp)))))
+    end
+    nnz = Ref{Int32}(0)
+    qln_check(ccall((:qln_problem_dims, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ref{Int32}), nlp.handle, 0, C_NULL, nnz))
+    rows = zeros(Int32, nnz[]); cols = zeros(Int32, nnz[])
+    qln_check(ccall((:qln_jacobian_structure, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}), nlp.handle, 0, rows, cols))
+    return [(Int(r) + 1, Int(c) + 1) for (r, c) in zip(rows, cols)]     # the ABI is 0-based
+end

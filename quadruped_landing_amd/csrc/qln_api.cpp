@@ -146,10 +146,12 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     int32_t m_max = 0, nnz_max = 0;
     for (int32_t b = 0; b < d->B; ++b) {
         const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b]);
+        co = round_up(co, align);
+        jo = round_up(jo, jalign);
         h->c_off[b] = co;
         h->j_off[b] = jo;
-        co = round_up(co + m, align);
-        jo = round_up(jo + nz, jalign);
+        co += m;   // no padding behind the last problem: for B == 1 the totals are exactly m_nlp / nnz,
+        jo += nz;  // so Ipopt-owned buffers of the reference's sizes can be passed as they are
         m_max = std::max(m_max, m);
         nnz_max = std::max(nnz_max, nz);
     }
