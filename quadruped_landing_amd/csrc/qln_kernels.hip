@@ -115,6 +115,57 @@ __device__ __forceinline__ void rk4_step(const double (&x)[15], const double (&u
     xn[14] = x[14] + u[4];
 }
 
+// Copy consecutive 1-KiB wave pieces (16 B per lane each) LDS -> global with all the batch's
+// ds_read_b128 in flight before the first store, so a batch pays the LDS latency once.  hipcc
+// re-interleaves any C++ formulation into read/wait/store through one register quad (or parks the
+// batch in scratch), so the reads and their single wait are inline asm; per cdna_hip_programming.md
+// section 5.7 the asm counts and waits for its own loads and no output is consumed before that wait.
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS address
+}
+
+__device__ __forceinline__ void drain6(uint32_t lds, double2* dst) {
+    v2f64 r0, r1, r2, r3, r4, r5;
+    asm volatile(
+        "ds_read_b128 %0, %6\n\t"
+        "ds_read_b128 %1, %6 offset:1024\n\t"
+        "ds_read_b128 %2, %6 offset:2048\n\t"
+        "ds_read_b128 %3, %6 offset:3072\n\t"
+        "ds_read_b128 %4, %6 offset:4096\n\t"
+        "ds_read_b128 %5, %6 offset:5120\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+        : "v"(lds)
+        : "memory");
+    v2f64* d = reinterpret_cast<v2f64*>(dst);
+    d[0 * kWave] = r0;
+    d[1 * kWave] = r1;
+    d[2 * kWave] = r2;
+    d[3 * kWave] = r3;
+    d[4 * kWave] = r4;
+    d[5 * kWave] = r5;
+}
+
+__device__ __forceinline__ void drain1(uint32_t lds, double2* dst) {
+    v2f64 r0;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(lds) : "memory");
+    *reinterpret_cast<v2f64*>(dst) = r0;
+}
+
+// REM full pieces starting at (lds, dst), both already offset by the lane
+template <int REM>
+__device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
+    if constexpr (REM >= 6) {
+        drain6(lds, dst);
+        drain_full<REM - 6>(lds + 6 * 1024, dst + 6 * kWave);
+    } else if constexpr (REM > 0) {
+        drain1(lds, dst);
+        drain_full<REM - 1>(lds + 1024, dst + kWave);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused constraint + Jacobian kernel.
 // ---------------------------------------------------------------------------------------------
@@ -258,16 +309,22 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             if (valid) {
                 Cb[o_ci + k] = init1 ? x[4] : x[6];
                 if (K >= kt) Cb[o_co + (K - kt)] = init1 ? x[6] : x[4];
-                Cb[o_bp + k] = x[1] - lb / 2 * fabs(sin(x[2]));
                 if (k == N - 2) {  // this lane also holds the terminal knot x_N
                     Cb[o_ci + k + 1] = init1 ? xnext[4] : xnext[6];
                     if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = init1 ? xnext[6] : xnext[4];
-                    Cb[o_bp + k + 1] = xnext[1] - lb / 2 * fabs(sin(xnext[2]));
                 }
                 // dynamics residuals: 15 per knot, knot-major and contiguous in c
                 // (src/constraints.jl:14-18); transposed through LDS so the store is coalesced
 #pragma unroll
                 for (int i = 0; i < 15; ++i) s_c[lane * 15 + i] = xn[i] - xnext[i];
+            }
+            // clearance rows (src/constraints.jl:98-113): one lane per knot of the slice, one sin() per
+            // wave; the terminal knot rides on lane nk of the last chunk
+            {
+                const bool own = valid || (last_chunk && lane == nk);
+                const double* zk = s_z + 20 * (own ? lane : 0);
+                const double cl = zk[1] - lb / 2 * fabs(sin(zk[2]));
+                if (own) Cb[o_bp + kc0 + lane] = cl;
             }
             wave_lds_sync();
             {
@@ -291,7 +348,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             // nothing of the value phase is kept: x, u are re-read from the staged slice, so the two
             // phases' register sets do not add up (a spill reload would cost a vmcnt(0) drain)
             wave_lds_sync();
-            double x[14], F1x, F1y, F2x, F2y, h, th_next;
+            double x[14], F1x, F1y, F2x, F2y, h;
 #pragma unroll
             for (int i = 0; i < 14; ++i) x[i] = zl[i];
             F1x = zl[15];
@@ -299,7 +356,15 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             F2x = zl[17];
             F2y = zl[18];
             h = zl[19];
-            th_next = zl[22];
+            // clearance d/dtheta (src/constraints.jl:269-273; theta == 0 takes the + branch): one lane
+            // per knot of the slice, one cos() per wave; the terminal knot x_N rides on lane nk of the
+            // last chunk
+            {
+                const bool own = valid || (last_chunk && lane == nk);
+                const double th = s_z[20 * (own ? lane : 0) + 2];
+                const double cth = cos(th);
+                if (own) Vb[kBlk * (N - 1) + kc0 + lane] = (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
+            }
             wave_lds_sync();
             {
                 // structural zeros of the tile: written here, never touched by the value writes below
@@ -310,13 +375,6 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                     if (i < T * kBlk / 2) s_j2[i] = zero2;
                 }
             }
-            // clearance d/dtheta (src/constraints.jl:269-273; theta == 0 takes the + branch)
-            if (valid) {
-                double* Vt = Vb + kBlk * (N - 1);
-                Vt[k] = (x[2] > 0) ? (-lb / 2 * cos(x[2])) : (lb / 2 * cos(x[2]));
-                if (k == N - 2) Vt[k + 1] = (th_next > 0) ? (-lb / 2 * cos(th_next)) : (lb / 2 * cos(th_next));
-            }
-
             // ---- base quantities of the step block's 85 non-zeros (closed form, see header) ----
             const double m1 = f1free ? 1.0 : 0.0, m2 = f2free ? 1.0 : 0.0;
             const double keep = jump ? 0.0 : 1.0;  // jump*_jacobian() rows 5,7,11..15 (slot 15 too: quirk Q1)
@@ -419,38 +477,23 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 wave_lds_sync();
                 {
                     // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
-                    double2* __restrict__ dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
+                    double2* dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
                     const int np = nkt * (kBlk / 2);
                     constexpr int kPieces = T * kBlk / 2;   // 16-byte pieces in a full tile
                     constexpr int kFull = kPieces / kWave;  // unpredicated wave instructions
-                    constexpr int kGroup = 6;               // LDS reads in flight per batch
                     if (nkt == T) {
-#pragma unroll
-                        for (int g0 = 0; g0 < kFull; g0 += kGroup) {
-                            double2 r[kGroup];
-#pragma unroll
-                            for (int j = 0; j < kGroup; ++j)
-                                if (g0 + j < kFull) r[j] = s_j2[(g0 + j) * kWave + lane];
-#pragma unroll
-                            for (int j = 0; j < kGroup; ++j)
-                                if (g0 + j < kFull) dst[(g0 + j) * kWave + lane] = r[j];
-                        }
+                        drain_full<kFull>(lds_offset(s_j2 + lane), dst + lane);
                         if (kPieces % kWave) {
                             const int i = kFull * kWave + lane;
                             if (i < kPieces) dst[i] = s_j2[i];
                         }
                     } else {
+                        // last, partial sub-tile of a chunk: whole 6-piece batches, then a predicated tail
+                        int i0 = 0;
 #pragma unroll 1
-                        for (int g0 = 0; g0 * kWave < np; g0 += kGroup) {
-                            double2 r[kGroup];
-#pragma unroll
-                            for (int j = 0; j < kGroup; ++j) r[j] = s_j2[min((g0 + j) * kWave + lane, kPieces - 1)];
-#pragma unroll
-                            for (int j = 0; j < kGroup; ++j) {
-                                const int i = (g0 + j) * kWave + lane;
-                                if (i < np) dst[i] = r[j];
-                            }
-                        }
+                        for (; i0 + 6 * kWave <= np; i0 += 6 * kWave) drain6(lds_offset(s_j2 + i0 + lane), dst + i0 + lane);
+#pragma unroll 1
+                        for (int i = i0 + lane; i < np; i += kWave) dst[i] = s_j2[i];
                     }
                 }
                 wave_lds_sync();
@@ -560,8 +603,13 @@ template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
     dim3 grid(nb), block(kWave);
+    // experiment knob: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
+    static const unsigned pad = [] {
+        const char* e = getenv("QLN_PAD_LDS");
+        return e ? (unsigned)atoi(e) : 0u;
+    }();
     if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, pad, stream, p, b_begin, Z, c, vals, flags);
     else if (c)
         hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
     else
@@ -590,6 +638,9 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 1: return launch_cj_t<5, 40, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 2: return launch_cj_t<4, 32, 4>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 3: return launch_cj_t<6, 48, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 4: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 5: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 7: return launch_cj_t<8, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         default: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
     }
 }

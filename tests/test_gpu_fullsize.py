@@ -80,9 +80,9 @@ def test_full_size_configs(B, N, ragged):
         cp = nlp.eval_c((Z.view(B, -1) + eps * d).reshape(-1).contiguous())
         cm = nlp.eval_c((Z.view(B, -1) - eps * d).reshape(-1).contiguous())
         stride_c = nlp.c_off[1] - nlp.c_off[0]
-        fd = ((cp - cm) / (2 * eps)).view(B, stride_c)[:nb, 29 : 29 + 15 * (N - 1)].reshape(nb, N - 1, 15)
+        fd = ((cp - cm) / (2 * eps))[: nb * stride_c].view(nb, stride_c)[:, 29 : 29 + 15 * (N - 1)].reshape(nb, N - 1, 15)
         stride_j = nlp.j_off[1] - nlp.j_off[0]
-        blocks = v.view(B, stride_j)[:nb, : 300 * (N - 1)].reshape(nb, N - 1, 20, 15)  # column-major 15x20
+        blocks = v[: nb * stride_j].view(nb, stride_j)[:, : 300 * (N - 1)].reshape(nb, N - 1, 20, 15)  # column-major 15x20
         dz = d[:nb, : 20 * (N - 1)].reshape(nb, N - 1, 20)
         nxt = (20 * (torch.arange(N - 1, device="cuda") + 1))[:, None] + torch.arange(15, device="cuda")[None, :]
         dxn = d[:nb][:, nxt]  # perturbation of x_{k+1}: (nb, N-1, 15)
