@@ -20,6 +20,53 @@ __global__ __launch_bounds__(64) void k_fill_region(double2* __restrict__ p, int
     double2* q = p + blockIdx.x * stride2;
     for (int i = threadIdx.x; i < region2; i += 64) q[i] = v;
 }
+// B2: the evaluator's store structure without its arithmetic: one wave per region, a T*2400-B LDS tile
+// (limits residency exactly like the real kernel), sub-tiles drained with ds_read_b128 + 1-KiB stores
+template <int T>
+__global__ __launch_bounds__(64) void k_fill_region_lds(double2* __restrict__ p, int nknots, size_t stride2) {
+    __shared__ double2 tile[T * 150];
+    for (int i = threadIdx.x; i < T * 150; i += 64) tile[i] = make_double2(1.0, 2.0);
+    __syncthreads();
+    double2* q = p + blockIdx.x * stride2;
+    for (int k0 = 0; k0 < nknots; k0 += T) {
+        const int np = min(T, nknots - k0) * 150;
+        double2* d = q + (size_t)k0 * 150;
+        for (int i = threadIdx.x; i < np; i += 64) d[i] = tile[i];
+    }
+}
+
+// B3: cache-policy variants of B (one wave per region, 16 B per lane)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fill_region_policy(double2* __restrict__ p, int region2, size_t stride2) {
+    v2f64 v = {1.0, 2.0};
+    v2f64* q = reinterpret_cast<v2f64*>(p + blockIdx.x * stride2);
+    for (int i = threadIdx.x; i < region2; i += 64) {
+        if (MODE == 0) q[i] = v;
+        if (MODE == 1) __builtin_nontemporal_store(v, &q[i]);
+        if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&q[i]), "v"(v) : "memory");
+        if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&q[i]), "v"(v) : "memory");
+        if (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(&q[i]), "v"(v) : "memory");
+        if (MODE == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(&q[i]), "v"(v) : "memory");
+    }
+}
+
+// B4: block -> region mappings and cooperative variants (how much does the width of the write front matter?)
+//  MAP 0: region = block; MAP 1: XCD-contiguous (blocks b, b+8, .. share an XCD: give each XCD a contiguous range)
+template <int MAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_fill_region_map(double2* __restrict__ p, int region2, size_t stride2, int nregions) {
+    const double2 v = make_double2(1.0, 2.0);
+    int r = blockIdx.x;
+    if (MAP == 1) r = (blockIdx.x % 8) * (nregions / 8) + blockIdx.x / 8;
+    double2* q = p + (size_t)r * stride2;
+    // WAVES waves share the region; wave w writes 1200-piece (19.2 KB) sub-tiles w, w+WAVES, ...
+    const int w = threadIdx.x / 64, lane = threadIdx.x % 64;
+    for (int t0 = w * 1200; t0 < region2; t0 += WAVES * 1200) {
+        const int n = min(1200, region2 - t0);
+        for (int i = lane; i < n; i += 64) q[t0 + i] = v;
+    }
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -47,13 +94,53 @@ int main() {
     CK(hipMalloc(&src, (size_t)B * 800 * 8));
     CK(hipMemset(buf, 0, nbytes)); CK(hipMemset(src, 0, (size_t)B * 800 * 8));
     const size_t wbytes = (size_t)B * region * 8;
-    for (int blocks : {2048, 4096, 8192}) {
+    for (int blocks : {256, 512, 1024, 2048, 4096, 8192}) {
         float ms = time_ms([&] { k_fill_flat<<<blocks, 256>>>((double2*)buf, wbytes / 16); });
         printf("fill_flat   blocks=%5d x256: %.3f ms  %.1f GB/s\n", blocks, ms, wbytes / ms / 1e6);
     }
     {
         float ms = time_ms([&] { k_fill_region<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
         printf("fill_region 1 wave/problem   : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+    }
+    {
+        float ms = time_ms([&] { k_fill_region_lds<8><<<B, 64>>>((double2*)buf, 39, stride / 2); });
+        printf("fill_region_lds T=8  (8 waves/CU) : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
+        printf("fill_region_lds T=16 (4 waves/CU) : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_lds<4><<<B, 64>>>((double2*)buf, 39, stride / 2); });
+        printf("fill_region_lds T=4  (16 waves/CU): %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_lds<2><<<B, 64>>>((double2*)buf, 39, stride / 2); });
+        printf("fill_region_lds T=2  (32 waves/CU): %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        float ms;
+        ms = time_ms([&] { k_fill_region_policy<0><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region plain      : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_policy<1><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region nt         : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_policy<2><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region sc1        : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_policy<3><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region sc0 sc1    : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_policy<4><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region sc1 nt     : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_policy<5><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2); });
+        printf("fill_region sc0 sc1 nt : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_map<1, 1><<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, B); });
+        printf("fill_region XCD-contig : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_map<0, 4><<<B, 256>>>((double2*)buf, (int)(region / 2), stride / 2, B); });
+        printf("fill_region 4 waves/rgn: %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_map<1, 4><<<B, 256>>>((double2*)buf, (int)(region / 2), stride / 2, B); });
+        printf("fill_region 4w + XCD   : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_map<0, 2><<<B, 128>>>((double2*)buf, (int)(region / 2), stride / 2, B); });
+        printf("fill_region 2 waves/rgn: %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        // XCD-contiguous + each XCD's range walked by a tight front: region r of XCD x = x*(B/8) + j
+        ms = time_ms([&] { k_fill_region_map<1, 1><<<B, 64>>>((double2*)buf, 1200 * 2, 1200 * 2, B * 2); });
+        printf("fill 38KB regions XCDc : %.3f ms  %.1f GB/s\n", ms, (double)B * 2 * 2400 * 16 / ms / 1e6);
+        ms = time_ms([&] { CK(hipMemsetAsync(buf, 0, wbytes, 0)); });
+        printf("hipMemsetAsync         : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
+        ms = time_ms([&] { k_fill_flat<<<8192, 256>>>((double2*)buf, wbytes / 16); });
+        printf("fill_flat 8192x256     : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
     }
     const size_t n = (size_t)B * 795;
     {

@@ -49,6 +49,18 @@ constexpr int kBlk = 300;  // 15 x 20 doubles per step block
 #define QLN_STAMP(i) do { } while (0)
 #endif
 
+// Workgroups are observed to be dealt round-robin over the 8 XCDs (blocks b and b+8 share one;
+// MI355X_MICROARCH.md "Workgroup dispatch").  Giving each XCD a CONTIGUOUS range of problems makes
+// every XCD's L2/TLB see one sequential write front instead of every 8th 100-KB region: a pure
+// fill of the evaluator's store shape goes from ~5.8 to ~6.8 TB/s with this map alone
+// (profiles/r01_store_ceiling.txt).  Placement is a speed matter only: any dispatch order computes
+// the same results.
+__device__ __forceinline__ int xcd_contiguous_index(int block, int n) {
+    const int per_xcd = (n + 7) >> 3;
+    return (block & 7) * per_xcd + (block >> 3);  // may be >= n for the last blocks: caller checks
+}
+__host__ inline unsigned xcd_grid(int n) { return 8u * (unsigned)((n + 7) / 8); }
+
 // Every workgroup of the hot kernel is ONE wavefront, so cross-lane hand-offs through LDS need no
 // s_barrier: the LDS executes a wave's DS instructions in issue order.  What is needed is that the
 // compiler keeps that order; a wavefront-scope fence plus the (instruction-less) wave barrier do
@@ -174,9 +186,9 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 //      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
 // W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
 template <int T, int KC, int W, bool WITH_C, bool WITH_J>
-__global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, const double* __restrict__ Z,
-                                                              double* __restrict__ C, double* __restrict__ V,
-                                                              uint32_t flags) {
+__global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
+                                                              const double* __restrict__ Z, double* __restrict__ C,
+                                                              double* __restrict__ V, uint32_t flags) {
     // LDS: one tile of T dense step blocks.  Before the Jacobian phase of a chunk the same bytes
     // hold the staged Z slice (20*64+15 doubles at offset 0) and, behind it, the chunk's dynamics
     // residuals (64*15 doubles at offset kCStage).
@@ -190,7 +202,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     double* const s_c = s_j + kCStage;
 
     const int lane = threadIdx.x;
-    const int b = b_begin + blockIdx.x;
+    const int bl = xcd_contiguous_index(blockIdx.x, nb);
+    if (bl >= nb) return;  // wave-uniform
+    const int b = b_begin + bl;
     QLN_STAMP(0);
     const int N = P.N;
     const int kt = P.k_trans[b];
@@ -507,7 +521,8 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
 // constants only (qln_jacobian_init_constants)
 __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, double* __restrict__ V) {
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;
     const int N = P.N;
     const int kt = P.k_trans[b];
     double* Vc = V + P.j_off[b] + kBlk * (N - 1) + N;
@@ -546,7 +561,8 @@ __device__ __forceinline__ double dotn(const double* a, const double* v, int n) 
 __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
     __shared__ double s_term[kWave];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;
     const int N = P.N;
     const double* Zb = Z + (int64_t)b * P.z_stride;
     const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
@@ -585,9 +601,9 @@ __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const
                                                            double* __restrict__ G) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
-    const int b = blockIdx.x;  // gridDim.x carries the batch (gridDim.y is limited to 65535)
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);  // gridDim.x carries the batch (gridDim.y <= 65535)
     const int i = blockIdx.y * blockDim.x + threadIdx.x;
-    if (i >= n_nlp) return;
+    if (b >= P.B || i >= n_nlp) return;
     const double* Zb = Z + (int64_t)b * P.z_stride;
     double* Gb = G + (int64_t)b * P.z_stride;
     const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
@@ -602,18 +618,18 @@ __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const
 template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
-    dim3 grid(nb), block(kWave);
+    dim3 grid(xcd_grid(nb)), block(kWave);
     // experiment knob: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
         const char* e = getenv("QLN_PAD_LDS");
         return e ? (unsigned)atoi(e) : 0u;
     }();
     if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, pad, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
     else if (c)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     else
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true>), grid, block, 0, stream, p, b_begin, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     return hipGetLastError();
 }
 
@@ -646,18 +662,18 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
 }
 
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream) {
-    hipLaunchKernelGGL(k_jacobian_constants, dim3(p.B), dim3(kWave), 0, stream, p, vals);
+    hipLaunchKernelGGL(k_jacobian_constants, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, vals);
     return hipGetLastError();
 }
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
-    hipLaunchKernelGGL(k_objective, dim3(p.B), dim3(kWave), 0, stream, p, Z, f);
+    hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
     return hipGetLastError();
 }
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
     const int n_nlp = 20 * p.N - 5;
-    dim3 grid(p.B, (n_nlp + 255) / 256);
+    dim3 grid(xcd_grid(p.B), (n_nlp + 255) / 256);
     hipLaunchKernelGGL(k_objective_gradient, grid, dim3(256), 0, stream, p, Z, grad);
     return hipGetLastError();
 }
