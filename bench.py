@@ -105,9 +105,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("QLN_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
@@ -115,22 +117,24 @@ def main():
     f = nlp.new_f()
     K, W = args.steps, args.warmup
 
+    multi = world > 1 or force_dist
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # warmup (untimed): W launches, one objective pass, and one gather so RCCL is initialised
     nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
     nlp.eval_f(Z, f)
-    if world > 1:
+    if multi:
         D.gather_results(f, c)
     barrier()
 
     t0 = time.perf_counter()
     ms_each = nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=K)  # K launches, HIP events around each
     t_gather = 0.0
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         tg = time.perf_counter()
         nlp.eval_f(Z, f)
@@ -179,7 +183,7 @@ def main():
                            "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms,
                            "launch_ms_min": float(np.min(ms_each)), "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N)}
-        if world > 1:
+        if multi:
             out["gather_ms"] = t_gather * 1e3
         if world == 1 and not args.no_other and args.workload != "config2":
             b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank)
@@ -192,7 +196,7 @@ def main():
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqln_hip.so")
+# QLN_LIB_PATH lets the A/B measurement scripts under bench/ load another in-tree build of the same ABI
+LIB_PATH = os.environ.get("QLN_LIB_PATH") or os.path.join(_HERE, "csrc", "libqln_hip.so")
 
 QLN_OK = 0
 QLN_ERR_INVALID_ARGUMENT = -1

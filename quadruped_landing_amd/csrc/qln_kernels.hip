@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     constexpr int kZSlice = KC * 20 + 15;
     constexpr int kCStage = (kZSlice + 1) & ~1;
     static_assert(T * kBlk >= kCStage + KC * 15, "Z slice + residual stage must fit in the tile they alias");
+    static_assert(T * kBlk >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
     __shared__ double2 s_j2[T * kBlk / 2];
     double* const s_j = reinterpret_cast<double*>(s_j2);
     double* const s_z = s_j;
@@ -207,9 +208,30 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     const int b = b_begin + bl;
     QLN_STAMP(0);
     const int N = P.N;
+    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+
+    // The first chunk's slice of Z (and the boundary vectors for c1/c2) depends only on the kernel
+    // arguments and the block index, so its loads are issued before anything else: the per-problem
+    // descriptors (k_trans, init_mode, c_off, j_off) are then fetched in the shadow of this round
+    // trip instead of in front of it.  Every load of a slice is in flight before the first wait;
+    // indices past the slice are clamped, not predicated.
+    constexpr int kStageIters = (kZSlice + kWave - 1) / kWave;
+    double zr[kStageIters];
+    double bnd = 0.0;
+    {
+        const int nz0 = 20 * min(KC, N - 1) + 15;
+#pragma unroll
+        for (int it = 0; it < kStageIters; ++it) zr[it] = Zb[min(it * kWave + lane, nz0 - 1)];
+        if (WITH_C) {
+            // x0 / xf for c1 / c2 (src/constraints.jl:149-150): unconditional and in bounds
+            const double* bp = (lane < 15) ? P.x0 + (int64_t)b * 15 + lane : P.xf + (int64_t)b * 15 + (min(lane, 28) - 15);
+            bnd = *bp;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     const int kt = P.k_trans[b];
     const int im = P.init_mode[b];
-    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
     double* __restrict__ Cb = WITH_C ? C + P.c_off[b] : nullptr;
     double* __restrict__ Vb = WITH_J ? V + P.j_off[b] : nullptr;
 
@@ -260,28 +282,17 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
         const bool f2free = (mode == 1);
         const double* zl = s_z + 20 * (valid ? lane : 0);
 
-        // ---- stage the chunk's slice of Z: every load is issued before the first wait (one HBM
-        // round trip per chunk).  Indices past the slice are clamped, not predicated. -----------
+        // ---- stage the chunk's slice of Z through LDS (chunk 0 was requested at kernel entry) ----
         {
-            constexpr int kStageIters = (kZSlice + kWave - 1) / kWave;
-            double zr[kStageIters];
-            const double* __restrict__ zsrc = Zb + 20 * kc0;
+            if (!first_chunk) {
+                const double* __restrict__ zsrc = Zb + 20 * kc0;
 #pragma unroll
-            for (int it = 0; it < kStageIters; ++it) {
-                if (it * kWave < nz) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
-            }
-            // boundary data for c1 / c2 (src/constraints.jl:149-150): unconditional and in bounds so
-            // it joins the same round trip
-            double bnd = 0.0;
-            if (WITH_C) {
-                const double* bp = (lane < 15) ? P.x0 + (int64_t)b * 15 + lane : P.xf + (int64_t)b * 15 + (min(lane, 28) - 15);
-                bnd = *bp;
+                for (int it = 0; it < kStageIters; ++it) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
             }
             wave_lds_sync();  // the previous chunk's drain reads precede this chunk's staging writes
+            // (the tile has room for all kStageIters*64 doubles; what lies past the slice is never read)
 #pragma unroll
-            for (int it = 0; it < kStageIters; ++it) {
-                if (it * kWave < nz) s_z[it * kWave + lane] = zr[it];
-            }
+            for (int it = 0; it < kStageIters; ++it) s_z[it * kWave + lane] = zr[it];
             wave_lds_sync();
             if (WITH_C) {
                 // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),

@@ -24,7 +24,7 @@ def gather_to_root(t, dst: int = 0, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [t]
     world = dist.get_world_size(group)
     if dist.get_rank(group) == dst:
