@@ -656,19 +656,20 @@ extern "C" int qln_diag_set_stamps(void* dev_ptr) {
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
                                       double* vals, uint32_t flags, hipStream_t stream) {
     if (nb <= 0 || (!c && !vals)) return hipSuccess;
-    // tuning knob for experiments (QLN_VARIANT env var is read once); the default is what ships
+    // Shipping configuration: T=16 (38.4 KB tile, 4 waves per CU, one per SIMD) when the Jacobian is
+    // written, T=8 / 8 waves per CU for the constraint-only launch (profiles/r01_variants.txt).
+    // QLN_VARIANT (read once) selects other instantiations for A/B measurements.
     static const int variant = [] {
         const char* e = getenv("QLN_VARIANT");
         return e ? atoi(e) : 0;
     }();
     switch (variant) {
-        case 1: return launch_cj_t<5, 40, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
-        case 2: return launch_cj_t<4, 32, 4>(p, b_begin, nb, Z, c, vals, flags, stream);
-        case 3: return launch_cj_t<6, 48, 3>(p, b_begin, nb, Z, c, vals, flags, stream);
-        case 4: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
-        case 5: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
-        case 7: return launch_cj_t<8, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
-        default: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 1: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 2: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        default:
+            if (!vals) return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+            return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
     }
 }
 
