@@ -67,6 +67,40 @@ __global__ __launch_bounds__(64 * WAVES) void k_fill_region_map(double2* __restr
     }
 }
 
+// B5: interleaved-batch layout: regions of a group of G problems are stored piece-major (piece = 1 KiB = one
+// wave instruction): address = group_base + (piece * G + member) KiB.  Concurrent waves then write adjacent KiBs.
+template <int MAP>
+__global__ __launch_bounds__(64) void k_fill_interleaved(double2* __restrict__ p, int pieces, int G, int nregions) {
+    const double2 v = make_double2(1.0, 2.0);
+    int r = blockIdx.x;
+    if (MAP == 1) r = (blockIdx.x % 8) * (nregions / 8) + blockIdx.x / 8;
+    const int grp = r / G, mem = r % G;
+    double2* q = p + ((size_t)grp * pieces * G + mem) * 64 + threadIdx.x;
+    for (int i = 0; i < pieces; ++i) q[(size_t)i * G * 64] = v;
+}
+
+// B6: the proposed interleaved layout with the evaluator's real store structure: LDS tile of 16 knots (38400 B),
+// 512-B pieces (64 doubles), G members per group; one 1-KiB wave store covers two pieces (lanes 0-31 / 32-63).
+template <int G>
+__global__ __launch_bounds__(64) void k_fill_tile_interleaved(double2* __restrict__ p, int nknots, int nregions) {
+    __shared__ double2 tile[16 * 150];
+    for (int i = threadIdx.x; i < 16 * 150; i += 64) tile[i] = make_double2(1.0, 2.0);
+    __syncthreads();
+    const int r = (blockIdx.x % 8) * (nregions / 8) + blockIdx.x / 8;
+    const int grp = r / G, mem = r % G;
+    const int Q = (nknots * 2400 + 511) / 512;  // pieces per problem
+    const int lane = threadIdx.x;
+    // double2 index of this lane inside piece (2i + lane/32)
+    double2* base = p + ((size_t)grp * Q * G + mem) * 32 + (size_t)(lane >> 5) * G * 32 + (lane & 31);
+    for (int k0 = 0; k0 < nknots; k0 += 16) {
+        const int nb = min(16, nknots - k0) * 2400;        // bytes in this sub-tile
+        const size_t q0 = (size_t)k0 * 2400 / 512;          // first piece (16*2400 = 75 pieces exactly)
+        for (int i = 0; i * 1024 < nb; ++i) {
+            if (i * 1024 + lane * 16 < nb) base[(q0 + 2 * i) * G * 32] = tile[i * 64 + lane];
+        }
+    }
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -137,6 +171,21 @@ int main() {
         // XCD-contiguous + each XCD's range walked by a tight front: region r of XCD x = x*(B/8) + j
         ms = time_ms([&] { k_fill_region_map<1, 1><<<B, 64>>>((double2*)buf, 1200 * 2, 1200 * 2, B * 2); });
         printf("fill 38KB regions XCDc : %.3f ms  %.1f GB/s\n", ms, (double)B * 2 * 2400 * 16 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_interleaved<64><<<B, 64>>>((double2*)buf, 39, B); });
+        printf("tile-interleaved 512B G=64 : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_interleaved<32><<<B, 64>>>((double2*)buf, 39, B); });
+        printf("tile-interleaved 512B G=32 : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_interleaved<128><<<B, 64>>>((double2*)buf, 39, B); });
+        printf("tile-interleaved 512B G=128: %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
+        printf("fill_region_lds T=16 rr    : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        for (int G : {64}) {
+            const int pieces = 92;  // 94208 B per region
+            ms = time_ms([&] { k_fill_interleaved<1><<<B, 64>>>((double2*)buf, pieces, G, B); });
+            printf("interleaved G=%-5d XCDc: %.3f ms  %.1f GB/s\n", G, ms, (double)B * pieces * 1024 / ms / 1e6);
+            ms = time_ms([&] { k_fill_interleaved<0><<<B, 64>>>((double2*)buf, pieces, G, B); });
+            printf("interleaved G=%-5d rr  : %.3f ms  %.1f GB/s\n", G, ms, (double)B * pieces * 1024 / ms / 1e6);
+        }
         ms = time_ms([&] { CK(hipMemsetAsync(buf, 0, wbytes, 0)); });
         printf("hipMemsetAsync         : %.3f ms  %.1f GB/s\n", ms, wbytes / ms / 1e6);
         ms = time_ms([&] { k_fill_flat<<<8192, 256>>>((double2*)buf, wbytes / 16); });
