@@ -350,6 +350,11 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const double* zk = s_z + 20 * (own ? lane : 0);
                 const double cl = zk[1] - lb / 2 * fabs(sin(zk[2]));
                 if (own) Cb[o_bp + kc0 + lane] = cl;
+                if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
+                    const double* zn = s_z + 20 * nk;
+                    const double cn = zn[1] - lb / 2 * fabs(sin(zn[2]));
+                    if (lane == 0) Cb[o_bp + kc0 + nk] = cn;
+                }
             }
             wave_lds_sync();
             {
@@ -389,6 +394,11 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const double th = s_z[20 * (own ? lane : 0) + 2];
                 const double cth = cos(th);
                 if (own) Vb[kBlk * (N - 1) + kc0 + lane] = (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
+                if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
+                    const double tn = s_z[20 * nk + 2];
+                    const double ctn = cos(tn);
+                    if (lane == 0) Vb[kBlk * (N - 1) + kc0 + nk] = (tn > 0) ? (-lb / 2 * ctn) : (lb / 2 * ctn);
+                }
             }
             wave_lds_sync();
             {

@@ -339,3 +339,40 @@ class HybridNLP:
     def split_vals(self, vals_host, b: int = 0):
         _, nz = self.problem_dims(b)
         return np.asarray(vals_host)[self.j_off[b] : self.j_off[b] + nz]
+
+
+# ----------------------------------------------------------------------------- caller-side pieces of solve()
+
+
+def variable_bounds(N: int):
+    """Variable bounds exactly as `solve()` sets them (src/moi.jl:51-67), 0-based arrays (x_l, x_u).
+
+    Reproduces the reference's quirk Q6 on purpose: its "lower bound of F" lines index
+    `22+20(k-1)` and `24+20(k-1)` (1-based), which are yb_{k+1} and x1_{k+1}, not F1y/F2y (17, 19);
+    the Ipopt header of the shipped run confirms it ("variables with only lower bounds: 120",
+    src/main.ipynb:222).  Pass quirk_Q6=False to bound the forces instead.
+    """
+    return _variable_bounds(N, True)
+
+
+def _variable_bounds(N: int, quirk_Q6: bool):
+    n_nlp = num_primals(N)
+    x_l, x_u = np.full(n_nlp, -np.inf), np.full(n_nlp, np.inf)
+    for k in range(1, N + 1):
+        x_l[3 + 20 * (k - 1) - 1] = -np.pi / 2  # theta >= -pi/2
+        x_u[3 + 20 * (k - 1) - 1] = np.pi / 2
+        if k < N:
+            x_l[20 + 20 * (k - 1) - 1] = 0.001  # dt
+            x_u[20 + 20 * (k - 1) - 1] = 0.02
+            if quirk_Q6:
+                x_l[22 + 20 * (k - 1) - 1] = 0.0
+                x_l[24 + 20 * (k - 1) - 1] = 0.0
+            else:
+                x_l[17 + 20 * (k - 1) - 1] = 0.0
+                x_l[19 + 20 * (k - 1) - 1] = 0.0
+    return x_l, x_u
+
+
+def variable_bounds_forces(N: int):
+    """The bounds the comment in src/moi.jl:63 describes (F1y, F2y >= 0) -- not what the reference does."""
+    return _variable_bounds(N, False)

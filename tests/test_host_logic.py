@@ -81,3 +81,35 @@ def test_moi_surface_names():
                  "features_available", "initialize", "jacobian_structure"):
         assert callable(getattr(moi, name))
     assert moi.features_available(None) == ["Grad", "Jac"] and moi.initialize(None, ["Grad"]) is None
+
+
+def test_variable_bounds_reproduce_solve_including_quirk_Q6():
+    # src/main.ipynb:221-223: 1215 variables, 120 with only lower bounds, 121 with lower and upper bounds
+    x_l, x_u = Q.variable_bounds(61)
+    lower_only = np.isfinite(x_l) & ~np.isfinite(x_u)
+    both = np.isfinite(x_l) & np.isfinite(x_u)
+    assert x_l.size == 1215 and lower_only.sum() == 120 and both.sum() == 121
+    assert not (~np.isfinite(x_l) & np.isfinite(x_u)).any()
+    # theta in [-pi/2, pi/2] at every knot, dt in [0.001, 0.02]
+    assert x_l[2] == -np.pi / 2 and x_u[1202] == np.pi / 2 and x_l[19] == 0.001 and x_u[1199 - 20 + 20] == 0.02
+    # Q6: the zero lower bounds sit on yb_{k+1}, x1_{k+1} (0-based 21, 23), not on F1y, F2y (16, 18)
+    assert x_l[21] == 0.0 and x_l[23] == 0.0 and x_l[16] == -np.inf and x_l[18] == -np.inf
+    fl, _ = NLP.variable_bounds_forces(61)
+    assert fl[16] == 0.0 and fl[18] == 0.0 and fl[21] == -np.inf
+
+
+def test_trajectory_io_roundtrip(tmp_path, golden_dir):
+    import os
+    from quadruped_landing_amd import trajectory_io as TIO
+
+    Z = TIO.load_trajectory(os.path.join(golden_dir, "data_6.csv"))
+    assert Z.size == 1215
+    p = tmp_path / "z.csv"
+    TIO.save_trajectory(str(p), Z)
+    assert np.array_equal(TIO.load_trajectory(str(p), 61), Z)  # bit-exact round trip
+    tab = TIO.as_plot_table(Z)
+    assert tab.shape == (60, 20) and tab[0, 2] == Z[2] and tab[59, 15] == Z[59 * 20 + 15]
+    X, U = TIO.states_controls(Z)
+    assert X.shape == (61, 15) and U.shape == (60, 5)
+    with pytest.raises(ValueError):
+        TIO.load_trajectory(str(p), 40)
