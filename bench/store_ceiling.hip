@@ -101,6 +101,15 @@ __global__ __launch_bounds__(64) void k_fill_tile_interleaved(double2* __restric
     }
 }
 
+// B7: chunked XCD map: XCD x owns chunks of CH consecutive regions, chunks dealt round-robin over XCDs
+__global__ __launch_bounds__(64) void k_fill_region_chunked(double2* __restrict__ p, int region2, size_t stride2, int CH) {
+    const double2 v = make_double2(1.0, 2.0);
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;       // XCD label, sequence number on that XCD
+    const int r = ((s / CH) * 8 + x) * CH + (s % CH);
+    double2* q = p + (size_t)r * stride2;
+    for (int i = threadIdx.x; i < region2; i += 64) q[i] = v;
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -179,6 +188,10 @@ int main() {
         printf("tile-interleaved 512B G=128: %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
         printf("fill_region_lds T=16 rr    : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        for (int CH : {8, 32, 128, 512, 2048}) {
+            ms = time_ms([&] { k_fill_region_chunked<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, CH); });
+            printf("fill_region chunked XCD map CH=%-4d: %.3f ms  %.1f GB/s\n", CH, ms, wbytes / ms / 1e6);
+        }
         for (int G : {64}) {
             const int pieces = 92;  // 94208 B per region
             ms = time_ms([&] { k_fill_interleaved<1><<<B, 64>>>((double2*)buf, pieces, G, B); });

@@ -122,6 +122,11 @@ int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, u
 /* The fused hot path: eval_c! and jac_c! of every knot of every problem in one launch. */
 int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags);
 int qln_jacobian_init_constants(qln_handle* h, double* vals);
+/* The step before the path: the notebook's initial guess Z0 = packZ(nlp, Xguess, Uref)
+ * (src/main.ipynb:181-198, src/nlp.jl:94-102, src/ref_traj.jl:19-34) for every problem of the batch, written
+ * on the device in the handle's Z layout.  Needs k_trans >= 2 for every problem (the notebook divides by
+ * k_trans - 1). */
+int qln_initial_guess(qln_handle* h, double* Z);
 
 /* MOI mode: HOST pointers, synchronous (H2D, launch, D2H inside).  Same layouts. */
 int qln_eval_objective_host(qln_handle* h, const double* Z, double* f);

@@ -364,6 +364,18 @@ int qln_jacobian_init_constants(qln_handle* h, double* vals) {
     return QLN_OK;
 }
 
+int qln_initial_guess(qln_handle* h, double* Z) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");
+    for (int32_t b = 0; b < h->dims.B; ++b)
+        if (h->k_trans[b] < 2)
+            return fail(QLN_ERR_UNSUPPORTED, "qln_initial_guess: k_trans < 2 at problem " + std::to_string(b) +
+                                                 " (the notebook's rule divides by k_trans - 1)");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_initial_guess(h->p, Z, h->stream));
+    return QLN_OK;
+}
+
 // ------------------------------------------------------------------ host-pointer (MOI) mode
 
 int qln_eval_objective_host(qln_handle* h, const double* Z, double* f) {

@@ -30,5 +30,6 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream);
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream);
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream);
+hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t stream);
 
 }  // namespace qln

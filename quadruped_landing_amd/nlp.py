@@ -274,6 +274,12 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
         return vals
 
+    def initial_guess(self, out=None):
+        """Z0 of the notebook's initial-guess rule (src/main.ipynb:181-198) for every problem, on the device."""
+        out = self.new_Z() if out is None else out
+        _lib.check(_lib.lib().qln_initial_guess(self._h, self._check(out, self.dims.z_total, "Z")))
+        return out
+
     def time_c_and_jac(self, Z, c, vals, warmup: int, iters: int, write_constants: bool = False):
         """HIP-event duration (ms) of each of `iters` launches of the fused hot path."""
         ms = (C.c_float * iters)()

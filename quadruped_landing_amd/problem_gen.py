@@ -72,7 +72,8 @@ def initial_guess(N, k_trans, x0, xf, Uref):
     after[:, :, 14] = False
     X = np.where(after, np.broadcast_to(xf[:, None, :], X.shape), X)
     dtk = np.where(np.arange(1, N)[None, :] < np.asarray(k_trans)[:, None], 0.001, 0.02)
-    X[:, 1:, 14] = X[:, :1, 14] + np.cumsum(dtk, axis=1)
+    # Xguess[k+1][end] = Xguess[k][end] + dt_k, sequentially from Xguess[1][end] (src/main.ipynb:191-198)
+    X[:, :, 14] = np.cumsum(np.concatenate([X[:, :1, 14], dtk], axis=1), axis=1)
     return packZ(N, X, Uref)
 
 

@@ -274,3 +274,32 @@ def test_launches_follow_the_callers_stream():
     ref = oracle_batch(batch, nlp)
     ok = ~np.isnan(ref["c"])
     assert float(norm) == np.abs(ref["c"][ok]).max() or abs(float(norm) - np.abs(ref["c"][ok]).max()) <= 1e-12
+
+
+def test_initial_guess_on_device_is_bitwise_the_notebook_rule():
+    """Z0 = packZ(nlp, Xguess, Uref) built on the GPU equals the host generator (which equals
+    the oracle's restatement of src/main.ipynb:181-198) bit for bit."""
+    import torch
+    from oracle import oracle as O
+    from quadruped_landing_amd import HybridNLP, _lib, problem_gen as PG
+
+    nb = PG.notebook_problem()
+    nlp = HybridNLP(nb.model, nb.obj, nb.init_mode, nb.k_trans, nb.N, nb.x0, nb.xf)
+    Z0 = nlp.initial_guess().cpu().numpy()
+    _, xinit, xterm, _, Uref = O.notebook_problem()
+    assert np.array_equal(Z0, O.notebook_initial_guess(61, 21, xinit, xterm, Uref))
+
+    batch = PG.make_batch(300, 80, seed=12, ragged=True, noise=0.0)
+    batch.x0[:, 14] = np.random.default_rng(0).uniform(0, 1, size=batch.B)  # non-zero initial clocks
+    from quadruped_landing_amd.ref_traj import reference_trajectory
+    _, Uref = reference_trajectory(batch.model, batch.N, batch.k_trans, batch.xf, batch.init_mode, 0.009)
+    want = PG.initial_guess(batch.N, batch.k_trans, batch.x0, batch.xf, Uref)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf, z_stride=1600)
+    got = nlp.initial_guess().cpu().numpy().reshape(batch.B, 1600)[:, : nlp.n_nlp]
+    assert np.array_equal(got, want)
+    bad = PG.make_batch(2, 10, 4, 1)
+    bad.k_trans[0] = 1
+    n2 = HybridNLP(bad.model, bad.obj, bad.init_mode, bad.k_trans, bad.N, bad.x0, bad.xf)
+    with pytest.raises(_lib.QlnError) as ei:
+        n2.initial_guess()
+    assert ei.value.code == _lib.QLN_ERR_UNSUPPORTED
