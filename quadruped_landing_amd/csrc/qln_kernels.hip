@@ -138,6 +138,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS address
 }
 
+template <int STEP>
 __device__ __forceinline__ void drain6(uint32_t lds, double2* dst) {
     v2f64 r0, r1, r2, r3, r4, r5;
     asm volatile(
@@ -152,12 +153,12 @@ __device__ __forceinline__ void drain6(uint32_t lds, double2* dst) {
         : "v"(lds)
         : "memory");
     v2f64* d = reinterpret_cast<v2f64*>(dst);
-    d[0 * kWave] = r0;
-    d[1 * kWave] = r1;
-    d[2 * kWave] = r2;
-    d[3 * kWave] = r3;
-    d[4 * kWave] = r4;
-    d[5 * kWave] = r5;
+    d[0 * STEP] = r0;
+    d[1 * STEP] = r1;
+    d[2 * STEP] = r2;
+    d[3 * STEP] = r3;
+    d[4 * STEP] = r4;
+    d[5 * STEP] = r5;
 }
 
 __device__ __forceinline__ void drain1(uint32_t lds, double2* dst) {
@@ -167,14 +168,14 @@ __device__ __forceinline__ void drain1(uint32_t lds, double2* dst) {
 }
 
 // REM full pieces starting at (lds, dst), both already offset by the lane
-template <int REM>
+template <int REM, int STEP>
 __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
     if constexpr (REM >= 6) {
-        drain6(lds, dst);
-        drain_full<REM - 6>(lds + 6 * 1024, dst + 6 * kWave);
+        drain6<STEP>(lds, dst);
+        drain_full<REM - 6, STEP>(lds + 6 * 1024, dst + 6 * STEP);
     } else if constexpr (REM > 0) {
         drain1(lds, dst);
-        drain_full<REM - 1>(lds + 1024, dst + kWave);
+        drain_full<REM - 1, STEP>(lds + 1024, dst + STEP);
     }
 }
 
@@ -185,7 +186,7 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 // KC = knots per chunk = lanes that integrate a knot at a time (<= 64); the chunk's Z slice and
 //      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
 // W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
-template <int T, int KC, int W, bool WITH_C, bool WITH_J>
+template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool IL = false>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
                                                               double* __restrict__ V, uint32_t flags) {
@@ -511,24 +512,33 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 }
                 wave_lds_sync();
                 {
-                    // nkt*300 contiguous doubles; 16 B per lane, 1 KiB per wave instruction
-                    double2* dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb);
+                    // nkt*300 contiguous doubles of the problem; 16 B per lane, 1 KiB per wave instruction.
+                    // IL (timing experiment only): 512-B pieces of 64 problems interleaved.
+                    constexpr int kStep = IL ? 2 * 64 * 32 : kWave;  // double2 between consecutive wave instructions
+                    double2* dst;
+                    if (IL) {
+                        const int Q = (kBlk * (N - 1) * 8 + 511) / 512;
+                        const int64_t q0 = (int64_t)kb * kBlk * 8 / 512;
+                        dst = reinterpret_cast<double2*>(V) + ((int64_t)(b / 64) * Q * 64 + (b % 64)) * 32 +
+                              (q0 + (lane >> 5)) * (64 * 32) + (lane & 31);
+                    } else {
+                        dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb) + lane;
+                    }
                     const int np = nkt * (kBlk / 2);
                     constexpr int kPieces = T * kBlk / 2;   // 16-byte pieces in a full tile
                     constexpr int kFull = kPieces / kWave;  // unpredicated wave instructions
                     if (nkt == T) {
-                        drain_full<kFull>(lds_offset(s_j2 + lane), dst + lane);
+                        drain_full<kFull, kStep>(lds_offset(s_j2 + lane), dst);
                         if (kPieces % kWave) {
-                            const int i = kFull * kWave + lane;
-                            if (i < kPieces) dst[i] = s_j2[i];
+                            if (kFull * kWave + lane < kPieces) dst[kFull * kStep] = s_j2[kFull * kWave + lane];
                         }
                     } else {
-                        // last, partial sub-tile of a chunk: whole 6-piece batches, then a predicated tail
-                        int i0 = 0;
+                        // last, partial sub-tile of a chunk: whole 6-instruction batches, then a predicated tail
+                        int it = 0;
 #pragma unroll 1
-                        for (; i0 + 6 * kWave <= np; i0 += 6 * kWave) drain6(lds_offset(s_j2 + i0 + lane), dst + i0 + lane);
+                        for (; (it + 6) * kWave <= np; it += 6) drain6<kStep>(lds_offset(s_j2 + it * kWave + lane), dst + (int64_t)it * kStep);
 #pragma unroll 1
-                        for (int i = i0 + lane; i < np; i += kWave) dst[i] = s_j2[i];
+                        for (; it * kWave + lane < np; ++it) dst[(int64_t)it * kStep] = s_j2[it * kWave + lane];
                     }
                 }
                 wave_lds_sync();
@@ -675,6 +685,15 @@ __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __
 template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
+    if constexpr (T == 16) {
+        // timing experiment only (QLN_HACK_IL=1): step blocks written in the interleaved-batch layout
+        static const bool il = getenv("QLN_HACK_IL") && atoi(getenv("QLN_HACK_IL")) == 1;
+        if (il && c && vals) {
+            hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, true>), dim3(xcd_grid(nb)), dim3(kWave), 0, stream,
+                               p, b_begin, nb, Z, c, vals, flags);
+            return hipGetLastError();
+        }
+    }
     dim3 grid(xcd_grid(nb)), block(kWave);
     // experiment knob: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
