@@ -186,7 +186,7 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 // KC = knots per chunk = lanes that integrate a knot at a time (<= 64); the chunk's Z slice and
 //      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
 // W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
-template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool IL = false>
+template <int T, int KC, int W, bool WITH_C, bool WITH_J>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
                                                               double* __restrict__ V, uint32_t flags) {
@@ -513,17 +513,8 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 wave_lds_sync();
                 {
                     // nkt*300 contiguous doubles of the problem; 16 B per lane, 1 KiB per wave instruction.
-                    // IL (timing experiment only): 512-B pieces of 64 problems interleaved.
-                    constexpr int kStep = IL ? 2 * 64 * 32 : kWave;  // double2 between consecutive wave instructions
-                    double2* dst;
-                    if (IL) {
-                        const int Q = (kBlk * (N - 1) * 8 + 511) / 512;
-                        const int64_t q0 = (int64_t)kb * kBlk * 8 / 512;
-                        dst = reinterpret_cast<double2*>(V) + ((int64_t)(b / 64) * Q * 64 + (b % 64)) * 32 +
-                              (q0 + (lane >> 5)) * (64 * 32) + (lane & 31);
-                    } else {
-                        dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb) + lane;
-                    }
+                    constexpr int kStep = kWave;  // double2 between consecutive wave instructions
+                    double2* dst = reinterpret_cast<double2*>(Vb + (int64_t)kBlk * kb) + lane;
                     const int np = nkt * (kBlk / 2);
                     constexpr int kPieces = T * kBlk / 2;   // 16-byte pieces in a full tile
                     constexpr int kFull = kPieces / kWave;  // unpredicated wave instructions
@@ -685,15 +676,6 @@ __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __
 template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
-    if constexpr (T == 16) {
-        // timing experiment only (QLN_HACK_IL=1): step blocks written in the interleaved-batch layout
-        static const bool il = getenv("QLN_HACK_IL") && atoi(getenv("QLN_HACK_IL")) == 1;
-        if (il && c && vals) {
-            hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, true>), dim3(xcd_grid(nb)), dim3(kWave), 0, stream,
-                               p, b_begin, nb, Z, c, vals, flags);
-            return hipGetLastError();
-        }
-    }
     dim3 grid(xcd_grid(nb)), block(kWave);
     // experiment knob: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
