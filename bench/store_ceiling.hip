@@ -133,7 +133,7 @@ int main() {
     const size_t region = 11740, stride = 12880;            // doubles: dynamic Jacobian values / padded nnz per problem
     const size_t nbytes = (size_t)B * stride * 8;
     double *buf, *src;
-    CK(hipMalloc(&buf, nbytes));
+    CK(hipMalloc(&buf, (size_t)B * 16384 * 8));  // room for the pitch sweep
     CK(hipMalloc(&src, (size_t)B * 800 * 8));
     CK(hipMemset(buf, 0, nbytes)); CK(hipMemset(src, 0, (size_t)B * 800 * 8));
     const size_t wbytes = (size_t)B * region * 8;
@@ -188,7 +188,12 @@ int main() {
         printf("tile-interleaved 512B G=128: %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
         printf("fill_region_lds T=16 rr    : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
-        for (int CH : {8, 32, 128, 512, 2048}) {
+        for (size_t pitch : {(size_t)11744, (size_t)12880, (size_t)12896, (size_t)13056, (size_t)13312, (size_t)16384}) {
+            if ((size_t)B * pitch * 8 > nbytes + (size_t)B * 800 * 8) continue;
+            ms = time_ms([&] { k_fill_region_map<1, 1><<<B, 64>>>((double2*)buf, (int)(region / 2), pitch / 2, B); });
+            printf("fill_region XCD-contig pitch=%zu doubles: %.3f ms  %.1f GB/s\n", pitch, ms, wbytes / ms / 1e6);
+        }
+        for (int CH : {2048}) {
             ms = time_ms([&] { k_fill_region_chunked<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, CH); });
             printf("fill_region chunked XCD map CH=%-4d: %.3f ms  %.1f GB/s\n", CH, ms, wbytes / ms / 1e6);
         }
