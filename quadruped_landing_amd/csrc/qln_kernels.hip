@@ -569,72 +569,89 @@ __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, dou
 // Objective (src/costs.jl:6-16) -- one wavefront per problem, lane per knot, and the reference's
 // sequential left-to-right sum over knots done by lane 0 so the value rounds like eval_f.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double quad_form(const double* D, const double* v, int n) {
-    double s = (0.5 * (D[0] * v[0])) * v[0];
-    for (int i = 1; i < n; ++i) s = s + (0.5 * (D[i] * v[i])) * v[i];
-    return s;
-}
-__device__ __forceinline__ double dotn(const double* a, const double* v, int n) {
-    double s = a[0] * v[0];
-    for (int i = 1; i < n; ++i) s = s + a[i] * v[i];
-    return s;
-}
-
 __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
-    __shared__ double s_term[kWave];
+    // Lane = entry of Z for the products (coalesced reads of Z and of the [k][41] cost records), lane = knot for
+    // the reference's left-to-right sums (src/quadratic_cost.jl:44-52), lane 0 for the sequential sum over knots
+    // (src/costs.jl:9-15): every floating-point operation and its order is the reference's, so f is bit-identical.
+    constexpr int kKnots = 32;                       // knots per pass
+    __shared__ double s_quad[kKnots * 20];           // (0.5 * (D_i * z_i)) * z_i
+    __shared__ double s_lin[kKnots * 20];            // d_i * z_i
+    __shared__ double s_h[kKnots];
+    __shared__ double s_term[kKnots];
     const int lane = threadIdx.x;
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     if (b >= P.B) return;
     const int N = P.N;
-    const double* Zb = Z + (int64_t)b * P.z_stride;
-    const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+    const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
     double J = 0.0;
-    for (int k0 = 0; k0 < N; k0 += kWave) {
-        const int k = k0 + lane;
-        double term = 0.0;
-        if (k < N) {
-            const double* ck = cost + (int64_t)k * 41;
-            double xv[15], uv[5];
-            for (int i = 0; i < 15; ++i) xv[i] = Zb[20 * k + i];
-            if (k < N - 1) {
-                for (int i = 0; i < 5; ++i) uv[i] = Zb[20 * k + 15 + i];
-                // stagecost, src/quadratic_cost.jl:44-47
-                const double l = (((quad_form(ck, xv, 15) + dotn(ck + 20, xv, 15)) + quad_form(ck + 15, uv, 5)) +
-                                  dotn(ck + 35, uv, 5)) + ck[40];
-                term = uv[4] * l;  // hk * stagecost
-            } else {
-                // termcost, src/quadratic_cost.jl:49-52
-                term = (quad_form(ck, xv, 15) + dotn(ck + 20, xv, 15)) + ck[40];
+    for (int k0 = 0; k0 < N; k0 += kKnots) {
+        const int nk = min(kKnots, N - k0);
+        const int ne = min(20 * nk, 20 * N - 5 - 20 * k0);  // entries of Z in this pass (x_N has no controls)
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kKnots * 20 / kWave; ++it) {
+            const int e = it * kWave + lane;
+            if (e < ne) {
+                const int kk = e / 20, j = e - 20 * kk;
+                const double z = Zb[20 * k0 + e];
+                const double* ck = cost + (int64_t)(k0 + kk) * 41;
+                s_quad[e] = (0.5 * (ck[j] * z)) * z;     // Q or R slot j
+                s_lin[e] = ck[20 + j] * z;               // q or r slot j
+                if (j == 19) s_h[kk] = z;
             }
         }
-        s_term[lane] = term;
         __syncthreads();
-        if (lane == 0) {
-            const int n = min(kWave, N - k0);
-            for (int i = 0; i < n; ++i) J += s_term[i];
+        if (lane < nk) {
+            const int k = k0 + lane;
+            const double* q = s_quad + 20 * lane;
+            const double* l = s_lin + 20 * lane;
+            double a = q[0], bb = l[0];
+#pragma unroll
+            for (int i = 1; i < 15; ++i) {
+                a = a + q[i];
+                bb = bb + l[i];
+            }
+            const double ck40 = cost[(int64_t)k * 41 + 40];
+            double term;
+            if (k < N - 1) {
+                double cc = q[15], d = l[15];
+#pragma unroll
+                for (int i = 16; i < 20; ++i) {
+                    cc = cc + q[i];
+                    d = d + l[i];
+                }
+                term = s_h[lane] * ((((a + bb) + cc) + d) + ck40);  // hk * stagecost
+            } else {
+                term = (a + bb) + ck40;                             // termcost
+            }
+            s_term[lane] = term;
         }
         __syncthreads();
+        if (lane == 0)
+            for (int i = 0; i < nk; ++i) J += s_term[i];
     }
     if (lane == 0) F[b] = J;
 }
 
-// Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  One thread per entry.
+// Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  One workgroup per problem.
 __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const double* __restrict__ Z,
                                                            double* __restrict__ G) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
-    const int b = xcd_contiguous_index(blockIdx.x, P.B);  // gridDim.x carries the batch (gridDim.y <= 65535)
-    const int i = blockIdx.y * blockDim.x + threadIdx.x;
-    if (b >= P.B || i >= n_nlp) return;
-    const double* Zb = Z + (int64_t)b * P.z_stride;
-    double* Gb = G + (int64_t)b * P.z_stride;
-    const double* cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
-    const int k = i / 20, j = i - 20 * k;
-    const double* ck = cost + (int64_t)k * 41;
-    const double z = Zb[i];
-    // Q*x + q for j < 15, R*u + r for the controls: table slots [0,20) and [20,40)
-    const double lin = ck[j] * z + ck[20 + j];
-    Gb[i] = (k < N - 1) ? Zb[20 * k + 19] * lin : lin;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;
+    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+    double* __restrict__ Gb = G + (int64_t)b * P.z_stride;
+    const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+    for (int i = threadIdx.x; i < n_nlp; i += blockDim.x) {
+        const int k = i / 20, j = i - 20 * k;
+        const double* ck = cost + (int64_t)k * 41;
+        const double z = Zb[i];
+        // Q*x + q for j < 15, R*u + r for the controls: record slots [0,20) and [20,40)
+        const double lin = ck[j] * z + ck[20 + j];
+        Gb[i] = (k < N - 1) ? Zb[20 * k + 19] * lin : lin;
+    }
 }
 
 // Initial guess of the reference's notebook (src/main.ipynb:181-198) packed like packZ (src/nlp.jl:94-102),
@@ -738,9 +755,7 @@ hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t str
 }
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
-    const int n_nlp = 20 * p.N - 5;
-    dim3 grid(xcd_grid(p.B), (n_nlp + 255) / 256);
-    hipLaunchKernelGGL(k_objective_gradient, grid, dim3(256), 0, stream, p, Z, grad);
+    hipLaunchKernelGGL(k_objective_gradient, dim3(xcd_grid(p.B)), dim3(256), 0, stream, p, Z, grad);
     return hipGetLastError();
 }
 
