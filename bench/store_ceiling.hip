@@ -110,6 +110,17 @@ __global__ __launch_bounds__(64) void k_fill_region_chunked(double2* __restrict_
     for (int i = threadIdx.x; i < region2; i += 64) q[i] = v;
 }
 
+// B8: XCD-contiguous ranges, each XCD walking its range from a different phase (skew, in regions): the 8 write
+// fronts are then not a multiple of a large power of two apart
+__global__ __launch_bounds__(64) void k_fill_region_skew(double2* __restrict__ p, int region2, size_t stride2, int nregions, int skew) {
+    const double2 v = make_double2(1.0, 2.0);
+    const int per = nregions / 8;
+    const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int r = x * per + (sq + x * skew) % per;
+    double2* q = p + (size_t)r * stride2;
+    for (int i = threadIdx.x; i < region2; i += 64) q[i] = v;
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -129,11 +140,13 @@ template <class F> float time_ms(F f, int iters = 10) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     const int B = 65536;
     const size_t region = 11740, stride = 12880;            // doubles: dynamic Jacobian values / padded nnz per problem
     const size_t nbytes = (size_t)B * stride * 8;
     double *buf, *src;
-    CK(hipMalloc(&buf, (size_t)B * 16384 * 8));  // room for the pitch sweep
+    if (getenv("CONTIG")) { CK(hipExtMallocWithFlags((void**)&buf, (size_t)B * 16384 * 8, hipDeviceMallocContiguous)); printf("contiguous allocation\n"); }
+    else CK(hipMalloc(&buf, (size_t)B * 16384 * 8));  // room for the pitch sweep
     CK(hipMalloc(&src, (size_t)B * 800 * 8));
     CK(hipMemset(buf, 0, nbytes)); CK(hipMemset(src, 0, (size_t)B * 800 * 8));
     const size_t wbytes = (size_t)B * region * 8;
@@ -188,6 +201,10 @@ int main() {
         printf("tile-interleaved 512B G=128: %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
         printf("fill_region_lds T=16 rr    : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        for (int skew : {0, 1, 37, 333, 1021, 4099}) {
+            ms = time_ms([&] { k_fill_region_skew<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, B, skew); });
+            printf("fill_region XCD-contig skew=%-5d: %.3f ms  %.1f GB/s\n", skew, ms, wbytes / ms / 1e6);
+        }
         for (size_t pitch : {(size_t)11744, (size_t)12880, (size_t)12896, (size_t)13056, (size_t)13312, (size_t)16384}) {
             if ((size_t)B * pitch * 8 > nbytes + (size_t)B * 800 * 8) continue;
             ms = time_ms([&] { k_fill_region_map<1, 1><<<B, 64>>>((double2*)buf, (int)(region / 2), pitch / 2, B); });

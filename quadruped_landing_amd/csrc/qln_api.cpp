@@ -60,13 +60,9 @@ struct qln_handle {
     std::vector<int32_t> k_trans, init_mode;
     std::vector<int64_t> c_off, j_off;
     // device storage owned by the handle
-    int32_t* d_k_trans = nullptr;
-    int32_t* d_init_mode = nullptr;
-    double* d_x0 = nullptr;
-    double* d_xf = nullptr;
+    qln::ProblemDesc* d_desc = nullptr;
+    double* d_bnd = nullptr;
     double* d_cost = nullptr;
-    int64_t* d_c_off = nullptr;
-    int64_t* d_j_off = nullptr;
     // staging for host-pointer mode
     double* s_Z = nullptr;
     double* s_c = nullptr;
@@ -173,13 +169,23 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
         return code;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(QLN_ERR_HIP, "hipSetDevice failed"));
-    if ((rc = upload(&h->d_k_trans, d->k_trans, (size_t)d->B))) return bail(rc);
-    if ((rc = upload(&h->d_init_mode, d->init_mode, (size_t)d->B))) return bail(rc);
-    if ((rc = upload(&h->d_x0, d->x0, (size_t)d->B * 15))) return bail(rc);
-    if ((rc = upload(&h->d_xf, d->xf, (size_t)d->B * 15))) return bail(rc);
+    {
+        // one 32-byte descriptor record and one 30-double boundary record per problem
+        std::vector<qln::ProblemDesc> desc((size_t)d->B);
+        std::vector<double> bnd((size_t)d->B * 30);
+        for (int32_t b = 0; b < d->B; ++b) {
+            desc[b].k_trans = d->k_trans[b];
+            desc[b].init_mode = d->init_mode[b];
+            desc[b].c_off = h->c_off[b];
+            desc[b].j_off = h->j_off[b];
+            desc[b].reserved = 0;
+            std::memcpy(&bnd[(size_t)b * 30], d->x0 + (size_t)b * 15, 15 * sizeof(double));
+            std::memcpy(&bnd[(size_t)b * 30 + 15], d->xf + (size_t)b * 15, 15 * sizeof(double));
+        }
+        if ((rc = upload(&h->d_desc, desc.data(), desc.size()))) return bail(rc);
+        if ((rc = upload(&h->d_bnd, bnd.data(), bnd.size()))) return bail(rc);
+    }
     if ((rc = upload(&h->d_cost, d->cost, (size_t)d->cost_batch * d->N * QLN_COST_STRIDE))) return bail(rc);
-    if ((rc = upload(&h->d_c_off, h->c_off.data(), (size_t)d->B))) return bail(rc);
-    if ((rc = upload(&h->d_j_off, h->j_off.data(), (size_t)d->B))) return bail(rc);
 
     qln::BatchParams& P = h->p;
     P.B = d->B;
@@ -188,15 +194,11 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     P.mb = d->model.mb;
     P.mf = d->model.mf;
     P.lb = d->model.lb;
-    P.k_trans = h->d_k_trans;
-    P.init_mode = h->d_init_mode;
-    P.x0 = h->d_x0;
-    P.xf = h->d_xf;
+    P.desc = h->d_desc;
+    P.bnd = h->d_bnd;
     P.cost = h->d_cost;
     P.cost_batch = d->cost_batch;
     P.z_stride = z_stride;
-    P.c_off = h->d_c_off;
-    P.j_off = h->d_j_off;
     *out = h;
     return QLN_OK;
 }
@@ -204,8 +206,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
 int qln_destroy(qln_handle* h) {
     if (!h) return QLN_OK;
     (void)hipSetDevice(h->device);
-    void* bufs[] = {h->d_k_trans, h->d_init_mode, h->d_x0, h->d_xf, h->d_cost, h->d_c_off, h->d_j_off,
-                    h->s_Z,       h->s_c,         h->s_vals, h->s_f, h->s_grad};
+    void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete h;

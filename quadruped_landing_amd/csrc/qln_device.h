@@ -8,20 +8,26 @@
 
 namespace qln {
 
+// Per-problem descriptor, one 32-byte record per problem so that a wave fetches everything it needs to
+// start with ONE scalar load (k_trans / init_mode of HybridNLP, src/nlp.jl:17-19, and the output offsets).
+struct alignas(32) ProblemDesc {
+    int32_t k_trans;    // 1-based start index of mode 3
+    int32_t init_mode;  // 1 or 2
+    int64_t c_off;      // offset of the problem's constraint vector in c
+    int64_t j_off;      // offset of the problem's Jacobian values in vals (even)
+    int64_t reserved;
+};
+
 // Device-resident description of a batch (mirrors HybridNLP, src/nlp.jl:13-33, per problem).
 struct BatchParams {
     int32_t B;
     int32_t N;
     double g, mb, mf, lb;      // PlanarQuadruped, src/planar_quadruped.jl:11-20
-    const int32_t* k_trans;    // [B] 1-based start index of mode 3
-    const int32_t* init_mode;  // [B]
-    const double* x0;          // [B][15]
-    const double* xf;          // [B][15]
+    const ProblemDesc* desc;   // [B]
+    const double* bnd;         // [B][30]: x0 (15) then xf (15) of each problem
     const double* cost;        // [cost_batch][N][41]
     int32_t cost_batch;
     int64_t z_stride;
-    const int64_t* c_off;      // [B]
-    const int64_t* j_off;      // [B], even
 };
 
 // Fused eval_c! + jac_c! over problems [b_begin, b_begin + nb).  c or vals may be null.

@@ -225,16 +225,16 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
         for (int it = 0; it < kStageIters; ++it) zr[it] = Zb[min(it * kWave + lane, nz0 - 1)];
         if (WITH_C) {
             // x0 / xf for c1 / c2 (src/constraints.jl:149-150): unconditional and in bounds
-            const double* bp = (lane < 15) ? P.x0 + (int64_t)b * 15 + lane : P.xf + (int64_t)b * 15 + (min(lane, 28) - 15);
-            bnd = *bp;
+            bnd = P.bnd[(int64_t)b * 30 + min(lane, 29)];  // x0[lane] for lane < 15, xf[lane - 15] after
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    const int kt = P.k_trans[b];
-    const int im = P.init_mode[b];
-    double* __restrict__ Cb = WITH_C ? C + P.c_off[b] : nullptr;
-    double* __restrict__ Vb = WITH_J ? V + P.j_off[b] : nullptr;
+    const ProblemDesc pd = P.desc[b];  // one 32-byte scalar load
+    const int kt = pd.k_trans;
+    const int im = pd.init_mode;
+    double* __restrict__ Cb = WITH_C ? C + pd.c_off : nullptr;
+    double* __restrict__ Vb = WITH_J ? V + pd.j_off : nullptr;
 
     const double g = P.g, mb = P.mb, mf = P.mf, lb = P.lb;
     const double Ib = mb * (lb * lb) / 12;  // mb * lb^2 / 12, src/planar_quadruped.jl:41
@@ -546,8 +546,8 @@ __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, dou
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     if (b >= P.B) return;
     const int N = P.N;
-    const int kt = P.k_trans[b];
-    double* Vc = V + P.j_off[b] + kBlk * (N - 1) + N;
+    const int kt = P.desc[b].k_trans;
+    double* Vc = V + P.desc[b].j_off + kBlk * (N - 1) + N;
     const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
     for (int i = lane; i < n_const; i += kWave) {
         double v;
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     const int i = blockIdx.y * blockDim.x + threadIdx.x;
     if (b >= P.B || i >= n_nlp) return;
-    const int kt = P.k_trans[b], im = P.init_mode[b];
-    const double* x0 = P.x0 + (int64_t)b * 15;
-    const double* xf = P.xf + (int64_t)b * 15;
+    const int kt = P.desc[b].k_trans, im = P.desc[b].init_mode;
+    const double* x0 = P.bnd + (int64_t)b * 30;
+    const double* xf = x0 + 15;
     const int k = i / 20, j = i - 20 * k;  // 0-based knot, slot
     const int K = k + 1;                   // the notebook's 1-based k
     double v;
