@@ -9,12 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_p$i -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-other > $OUT/pmc_p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_p$i.log; exit 1; }
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_p$i -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/pmc_p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_p$i.log; exit 1; }
 done
 python3 $R/bench/pmc_summary.py k_constraint_jacobian $OUT/pmc_p* > $OUT/pmc_summary.txt
 python3 - <<PY

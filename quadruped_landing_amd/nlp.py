@@ -210,6 +210,30 @@ class HybridNLP:
     def new_vals(self):
         return _torch().zeros(self.dims.j_total, dtype=_torch().float64, device=self._dev())
 
+    def new_vals_placed(self, Z, c, trials: int = 4, launches: int = 3):
+        """Setup-time placement choice for the (large, long-lived) Jacobian buffer.
+
+        Where the driver places a multi-GB allocation physically changes the sustained store bandwidth of
+        the hot kernel by up to ~20 % on MI355X (profiles/r01_placement_sensitivity.txt),
+        and an allocation keeps its placement for its lifetime.  This allocates `trials` candidate buffers
+        (held simultaneously, so the driver cannot hand the same pages back), times `launches` launches of the
+        fused kernel on each, keeps the fastest and frees the others.  Returns (vals, [ms per trial]).
+        """
+        t = _torch()
+        cands, times = [], []
+        for _ in range(max(1, int(trials))):
+            v = self.new_vals()
+            self.init_jacobian_constants(v)
+            ms = self.time_c_and_jac(Z, c, v, warmup=1, iters=max(1, int(launches)))
+            cands.append(v)
+            times.append(float(np.median(ms)))
+        best = int(np.argmin(times))
+        vals = cands[best]
+        cands.clear()
+        del v
+        t.cuda.empty_cache()
+        return vals, times
+
     def new_f(self):
         return _torch().zeros(self.B, dtype=_torch().float64, device=self._dev())
 
