@@ -15,6 +15,11 @@
  * veneer a maintainer would add is integration/julia/HybridNLPHIP.jl; the Python
  * ctypes mirror used by the tests is quadruped_landing_amd/_lib.py.
  *
+ * Threading: a handle is not thread-safe; distinct handles are independent.  Batched (device-pointer)
+ * calls are asynchronous and ordered on the handle's stream; MOI-mode (host-pointer) calls return
+ * after the results are in the caller's buffers.  The library never allocates, frees or keeps caller
+ * buffers; it owns only its handle (descriptor copies and, for MOI mode, lazily allocated staging).
+ *
  * Layouts (all FP64, all offsets/strides in doubles):
  *   Z     problem b at Z + b*z_stride, length n_nlp = 20N-5,
  *         [x_1 u_1 x_2 u_2 ... x_{N-1} u_{N-1} x_N]           (src/nlp.jl:38-39,94-102)

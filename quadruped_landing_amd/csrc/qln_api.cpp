@@ -475,9 +475,10 @@ int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
         return fail(QLN_ERR_INVALID_ARGUMENT, "qln_time_constraint_and_jacobian: bad argument");
     if (int rc = check_vals(vals)) return rc;
     if (int rc = bind_device(h)) return rc;
-    std::vector<hipEvent_t> ev(2 * (size_t)iters);
-    for (auto& e : ev) QLN_HIP(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
     int rc = QLN_OK;
+    for (auto& e : ev)
+        if (rc == QLN_OK && hipEventCreate(&e) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventCreate failed");
     for (int32_t i = 0; i < warmup && rc == QLN_OK; ++i)
         if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream) != hipSuccess)
             rc = fail(QLN_ERR_HIP, "warmup launch failed");
@@ -491,7 +492,8 @@ int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
     for (int32_t i = 0; i < iters && rc == QLN_OK; ++i)
         if (hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess)
             rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
-    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }
 
