@@ -80,7 +80,8 @@ typedef struct qln_batch_desc {
     const int32_t* init_mode; /* [B], 1 or 2 */
     const double* x0;         /* [B][15] */
     const double* xf;         /* [B][15] */
-    const double* cost;       /* [cost_batch][N][41] per-knot diagonal QuadraticCost (obj vector) */
+    const double* cost;       /* [cost_batch][N][41] per-knot diagonal QuadraticCost (obj vector); NULL = none yet:
+                                 build it on the device with qln_set_lqr_cost before evaluating f / grad */
     int32_t cost_batch;       /* 1 = one table shared by all problems, or B */
     int64_t z_stride;         /* doubles between consecutive problems in Z/grad; 0 -> n_nlp (dense) */
     int32_t align;            /* c_off/j_off are rounded up to a multiple of this many doubles;
@@ -132,6 +133,15 @@ int qln_jacobian_init_constants(qln_handle* h, double* vals);
  * on the device in the handle's Z layout.  Needs k_trans >= 2 for every problem (the notebook divides by
  * k_trans - 1). */
 int qln_initial_guess(qln_handle* h, double* Z);
+/* The notebook's objective built on the device: obj[k] = LQRCost(Q, R, Xref[k], Uref[k]), k < N, and
+ * obj[N] = LQRCost(Qf, R*0, Xref[N], Uref[1]) (src/main.ipynb:158-161, src/quadratic_cost.jl:33-42) with Xref/Uref of
+ * reference_trajectory(model, N, k_trans, xf, init_mode, dt) (src/ref_traj.jl:6-39).  Q, Qf: 15 diagonal entries,
+ * R: 5.  per_problem != 0 builds one table per problem (k_trans / init_mode / xf may differ), else one shared table
+ * from problem 0.  Replaces any previous cost table of the handle. */
+int qln_set_lqr_cost(qln_handle* h, const double* Qdiag, const double* Rdiag, const double* Qfdiag, double dt,
+                     int per_problem);
+/* Copies the handle's cost table ([cost_batch][N][41]) to a host buffer; cost_batch is returned through *cost_batch. */
+int qln_get_cost(qln_handle* h, double* cost_host, int32_t* cost_batch);
 
 /* MOI mode: HOST pointers, synchronous (H2D, launch, D2H inside).  Same layouts. */
 int qln_eval_objective_host(qln_handle* h, const double* Z, double* f);

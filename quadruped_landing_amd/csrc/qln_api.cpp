@@ -110,7 +110,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     if (d->B < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: B must be >= 1");
     if (d->N < 2) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N must be >= 2");
     if (d->N > 50000000 / 20) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N too large for 32-bit indices");
-    if (!d->k_trans || !d->init_mode || !d->x0 || !d->xf || !d->cost)
+    if (!d->k_trans || !d->init_mode || !d->x0 || !d->xf)
         return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: null descriptor array");
     if (d->cost_batch != 1 && d->cost_batch != d->B)
         return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: cost_batch must be 1 or B");
@@ -185,7 +185,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
         if ((rc = upload(&h->d_desc, desc.data(), desc.size()))) return bail(rc);
         if ((rc = upload(&h->d_bnd, bnd.data(), bnd.size()))) return bail(rc);
     }
-    if ((rc = upload(&h->d_cost, d->cost, (size_t)d->cost_batch * d->N * QLN_COST_STRIDE))) return bail(rc);
+    if (d->cost && (rc = upload(&h->d_cost, d->cost, (size_t)d->cost_batch * d->N * QLN_COST_STRIDE))) return bail(rc);
 
     qln::BatchParams& P = h->p;
     P.B = d->B;
@@ -309,8 +309,54 @@ int qln_jacobian_structure(const qln_handle* h, int32_t b, int32_t* rows, int32_
 
 // ------------------------------------------------------------------ device-pointer mode
 
+static int check_cost(const qln_handle* h) {
+    if (!h->p.cost) return fail(QLN_ERR_INVALID_ARGUMENT, "no cost table: pass desc.cost or call qln_set_lqr_cost first");
+    return QLN_OK;
+}
+
+int qln_set_lqr_cost(qln_handle* h, const double* Qdiag, const double* Rdiag, const double* Qfdiag, double dt,
+                     int per_problem) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Qdiag || !Rdiag || !Qfdiag) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_set_lqr_cost: null weights");
+    if (int rc = bind_device(h)) return rc;
+    const int32_t cb = per_problem ? h->dims.B : 1;
+    double w[35];
+    std::memcpy(w, Qdiag, 15 * sizeof(double));
+    std::memcpy(w + 15, Rdiag, 5 * sizeof(double));
+    std::memcpy(w + 20, Qfdiag, 15 * sizeof(double));
+    double* d_w = nullptr;
+    double* d_cost = nullptr;
+    QLN_HIP(hipMalloc(reinterpret_cast<void**>(&d_w), sizeof(w)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cost), (size_t)cb * h->dims.N * QLN_COST_STRIDE * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, w, sizeof(w), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = qln::launch_lqr_cost(h->p, d_w, dt, d_cost, cb, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_w);
+    if (e != hipSuccess) {
+        if (d_cost) (void)hipFree(d_cost);
+        return fail(QLN_ERR_HIP, std::string("qln_set_lqr_cost: ") + hipGetErrorString(e));
+    }
+    if (h->d_cost) (void)hipFree(h->d_cost);
+    h->d_cost = d_cost;
+    h->p.cost = d_cost;
+    h->p.cost_batch = cb;
+    return QLN_OK;
+}
+
+int qln_get_cost(qln_handle* h, double* cost_host, int32_t* cost_batch) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
+    if (cost_batch) *cost_batch = h->p.cost_batch;
+    if (!cost_host) return QLN_OK;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(hipMemcpy(cost_host, h->p.cost, (size_t)h->p.cost_batch * h->dims.N * QLN_COST_STRIDE * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    return QLN_OK;
+}
+
 int qln_eval_objective(qln_handle* h, const double* Z, double* f) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
     if (!Z || !f) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective: null pointer");
     if (int rc = bind_device(h)) return rc;
     QLN_HIP(qln::launch_objective(h->p, Z, f, h->stream));
@@ -319,6 +365,7 @@ int qln_eval_objective(qln_handle* h, const double* Z, double* f) {
 
 int qln_eval_objective_gradient(qln_handle* h, const double* Z, double* grad) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
     if (!Z || !grad) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_gradient: null pointer");
     if (int rc = bind_device(h)) return rc;
     QLN_HIP(qln::launch_objective_gradient(h->p, Z, grad, h->stream));
@@ -381,6 +428,7 @@ int qln_initial_guess(qln_handle* h, double* Z) {
 
 int qln_eval_objective_host(qln_handle* h, const double* Z, double* f) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
     if (!Z || !f) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_host: null pointer");
     if (int rc = bind_device(h)) return rc;
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
@@ -394,6 +442,7 @@ int qln_eval_objective_host(qln_handle* h, const double* Z, double* f) {
 
 int qln_eval_objective_gradient_host(qln_handle* h, const double* Z, double* grad) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
     if (!Z || !grad) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_gradient_host: null pointer");
     if (int rc = bind_device(h)) return rc;
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;

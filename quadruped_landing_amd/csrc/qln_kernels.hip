@@ -690,6 +690,55 @@ __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __
     Z[(int64_t)b * P.z_stride + i] = v;
 }
 
+// LQR cost records of the notebook's objective (src/main.ipynb:158-161): obj[k] = LQRCost(Q, R, Xref[k], Uref[k])
+// for k < N, obj[N] = LQRCost(Qf, R*0, Xref[N], Uref[1]), with Xref/Uref of reference_trajectory
+// (src/ref_traj.jl:6-39) and LQRCost of src/quadratic_cost.jl:33-42, built on the device: one thread per
+// (problem, knot).  Same operation order as the host builder (quadruped_landing_amd/quadratic_cost.py), so
+// the records are bit-identical.  cost_batch == 1 builds one table from problem 0's descriptors.
+__global__ __launch_bounds__(256) void k_lqr_cost(BatchParams P, const double* __restrict__ QRQf /*15+5+15*/, double dt,
+                                                 double* __restrict__ cost, int cost_batch) {
+    const int N = P.N;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cost_batch * N) return;
+    const int b = t / N, k = t - b * N;
+    const int K = k + 1;
+    const int kt = P.desc[b].k_trans, im = P.desc[b].init_mode;
+    const double* xterm = P.bnd + (int64_t)b * 30 + 15;
+    const bool last = (k == N - 1);
+    const double* Qd = last ? QRQf + 20 : QRQf;
+    // Xref[:, k] = xterm with the clock slot = range(0, dt*(N-1), length=N)[k]  (numpy.linspace on the host)
+    double xr[15];
+    for (int i = 0; i < 14; ++i) xr[i] = xterm[i];
+    const double stop = dt * (double)(N - 1);
+    xr[14] = (N > 1) ? (last ? stop : (double)k * (stop / (double)(N - 1))) : 0.0;
+    // Uref[:, k] (the terminal record uses Uref[1] and R*0)
+    double ur[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    {
+        const int Ku = last ? 1 : K;
+        const bool before = (Ku <= kt - 1);
+        const int lead = (im == 1) ? 1 : 3, other = (im == 1) ? 3 : 1;
+        ur[lead] = before ? (-P.mb * P.g) : (-P.mb * P.g / 2);
+        ur[other] = before ? 0.0 : (-P.mb * P.g / 2);
+        ur[4] = before ? 0.001 : 0.02;
+    }
+    double* out = cost + ((int64_t)b * N + k) * 41;
+    double a = 0.0, bb = 0.0;
+    for (int i = 0; i < 15; ++i) {
+        out[i] = Qd[i];
+        out[20 + i] = (-Qd[i]) * xr[i];                    // q = -Q * xf
+        const double tq = (0.5 * (Qd[i] * xr[i])) * xr[i];
+        a = (i == 0) ? tq : a + tq;
+    }
+    for (int i = 0; i < 5; ++i) {
+        const double Ri = last ? QRQf[15 + i] * 0 : QRQf[15 + i];
+        out[15 + i] = Ri;
+        out[35 + i] = (-Ri) * ur[i];                       // r = -R * uf
+        const double tr = (0.5 * (Ri * ur[i])) * ur[i];
+        bb = (i == 0) ? tr : bb + tr;
+    }
+    out[40] = a + bb;                                      // c = 0.5*xf'Q*xf + 0.5*uf'R*uf
+}
+
 template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
@@ -744,6 +793,13 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
     hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_lqr_cost(const BatchParams& p, const double* qrqf, double dt, double* cost, int cost_batch,
+                           hipStream_t stream) {
+    const int n = cost_batch * p.N;
+    hipLaunchKernelGGL(k_lqr_cost, dim3((n + 255) / 256), dim3(256), 0, stream, p, qrqf, dt, cost, cost_batch);
     return hipGetLastError();
 }
 

@@ -107,13 +107,16 @@ class HybridNLP:
         self.xf = np.ascontiguousarray(np.broadcast_to(np.asarray(xf, dtype=np.float64), (B, n)))
         self.k_trans = np.ascontiguousarray(np.broadcast_to(np.asarray(k_trans, dtype=np.int32), (B,)))
         self.init_mode = np.ascontiguousarray(np.broadcast_to(np.asarray(init_mode, dtype=np.int32), (B,)))
-        obj = np.ascontiguousarray(obj, dtype=np.float64)
-        if obj.shape == (self.N, _lib.COST_STRIDE):
+        if obj is None:  # no cost yet: build it on the device with set_lqr_cost()
             self.cost_batch = 1
-        elif obj.shape == (B, self.N, _lib.COST_STRIDE):
-            self.cost_batch = B
         else:
-            raise ValueError(f"obj must have shape (N,41) or (B,N,41), got {obj.shape}")
+            obj = np.ascontiguousarray(obj, dtype=np.float64)
+            if obj.shape == (self.N, _lib.COST_STRIDE):
+                self.cost_batch = 1
+            elif obj.shape == (B, self.N, _lib.COST_STRIDE):
+                self.cost_batch = B
+            else:
+                raise ValueError(f"obj must have shape (N,41) or (B,N,41), got {obj.shape}")
         self.obj = obj
         self.device = int(device)
 
@@ -124,7 +127,8 @@ class HybridNLP:
         ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
         d.k_trans = self.k_trans.ctypes.data_as(ip)
         d.init_mode = self.init_mode.ctypes.data_as(ip)
-        d.x0, d.xf, d.cost = self.x0.ctypes.data_as(dp), self.xf.ctypes.data_as(dp), self.obj.ctypes.data_as(dp)
+        d.x0, d.xf = self.x0.ctypes.data_as(dp), self.xf.ctypes.data_as(dp)
+        d.cost = self.obj.ctypes.data_as(dp) if self.obj is not None else None
         d.cost_batch, d.z_stride, d.align = self.cost_batch, int(z_stride), int(align)
         h = C.c_void_p()
         _lib.check(L.qln_create(C.byref(d), self.device, C.byref(h)))
@@ -303,6 +307,23 @@ class HybridNLP:
         out = self.new_Z() if out is None else out
         _lib.check(_lib.lib().qln_initial_guess(self._h, self._check(out, self.dims.z_total, "Z")))
         return out
+
+    def set_lqr_cost(self, Q, R, Qf, dt: float, per_problem: bool = False):
+        """The notebook's objective (src/main.ipynb:158-161) built on the device from the handle's own k_trans /
+        init_mode / xf; Q, Qf: 15 diagonal entries, R: 5."""
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(15)
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(5)
+        Qf = np.ascontiguousarray(Qf, dtype=np.float64).reshape(15)
+        _lib.check(_lib.lib().qln_set_lqr_cost(self._h, Q.ctypes.data, R.ctypes.data, Qf.ctypes.data, float(dt),
+                                               1 if per_problem else 0))
+        self.cost_batch = self.B if per_problem else 1
+
+    def get_cost(self):
+        cb = C.c_int32()
+        _lib.check(_lib.lib().qln_get_cost(self._h, None, C.byref(cb)))
+        out = np.zeros((cb.value, self.N, _lib.COST_STRIDE))
+        _lib.check(_lib.lib().qln_get_cost(self._h, out.ctypes.data, C.byref(cb)))
+        return out[0] if cb.value == 1 else out
 
     def time_c_and_jac(self, Z, c, vals, warmup: int, iters: int, write_constants: bool = False):
         """HIP-event duration (ms) of each of `iters` launches of the fused hot path."""

@@ -29,7 +29,7 @@ class LandingBatch:
     init_mode: np.ndarray  # (B,) int32
     x0: np.ndarray         # (B,15)
     xf: np.ndarray         # (B,15)
-    obj: np.ndarray        # (N,41) or (B,N,41)
+    obj: np.ndarray | None  # (N,41) or (B,N,41); None when the cost is built on the device
     Z: np.ndarray          # (B, 20N-5)
 
     @property
@@ -78,7 +78,8 @@ def initial_guess(N, k_trans, x0, xf, Uref):
 
 
 def make_batch(B: int, N: int = 40, k_trans=14, init_mode=1, *, seed: int = 0, ragged: bool = False,
-               noise: float = 0.05, dt: float = 0.009, model: PlanarQuadruped | None = None) -> LandingBatch:
+               noise: float = 0.05, dt: float = 0.009, model: PlanarQuadruped | None = None,
+               build_obj: bool = True) -> LandingBatch:
     """BASELINE.json configs 2/3/5 (uniform k_trans/init_mode) or config 4 (ragged=True:
     per-problem k_trans ~ U{2..N-1}, init_mode ~ U{1,2}, h ~ U(0.001, 0.02))."""
     model = model or PlanarQuadruped()
@@ -99,7 +100,9 @@ def make_batch(B: int, N: int = 40, k_trans=14, init_mode=1, *, seed: int = 0, r
     x0[swap, 10:12], x0[swap, 12:14] = x0[swap, 12:14].copy(), x0[swap, 10:12].copy()
     xf = np.tile(terminal_state(model), (B, 1))
     Xref, Uref = reference_trajectory(model, N, kt, xf, im, dt)
-    if ragged:
+    if not build_obj:
+        obj = None  # the caller builds it on the device: HybridNLP.set_lqr_cost(Q_DIAG, R_DIAG, Q_DIAG, dt, per_problem=ragged)
+    elif ragged:
         obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref, Uref)
     else:
         obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref[0], Uref[0])

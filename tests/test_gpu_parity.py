@@ -303,3 +303,29 @@ def test_initial_guess_on_device_is_bitwise_the_notebook_rule():
     with pytest.raises(_lib.QlnError) as ei:
         n2.initial_guess()
     assert ei.value.code == _lib.QLN_ERR_UNSUPPORTED
+
+
+def test_lqr_cost_built_on_device_is_bitwise_the_host_builder():
+    """LQRCost records (src/quadratic_cost.jl:33-42) over reference_trajectory (src/ref_traj.jl)
+    built by qln_set_lqr_cost equal the host builder bit for bit, shared and per-problem; f and grad follow."""
+    from quadruped_landing_amd import HybridNLP, _lib, problem_gen as PG
+
+    for ragged in (False, True):
+        batch = PG.make_batch(96, 33, 11, 2, seed=21, ragged=ragged)
+        nlp = HybridNLP(batch.model, None, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+        Z = nlp.upload_Z(batch.Z)
+        with pytest.raises(_lib.QlnError):
+            nlp.eval_f(Z)  # no cost table yet
+        Qw = PG.Q_DIAG.copy()
+        Qw[14] = 0.7  # weight on the clock slot too, so the time ramp of Xref matters
+        nlp.set_lqr_cost(Qw, PG.R_DIAG, PG.Q_DIAG * 3.0, 0.009, per_problem=ragged)
+        from quadruped_landing_amd.ref_traj import reference_trajectory
+        from quadruped_landing_amd.quadratic_cost import lqr_objective
+        Xref, Uref = reference_trajectory(batch.model, batch.N, batch.k_trans, batch.xf, batch.init_mode, 0.009)
+        want = lqr_objective(Qw, PG.R_DIAG, PG.Q_DIAG * 3.0, Xref, Uref) if ragged else \
+            lqr_objective(Qw, PG.R_DIAG, PG.Q_DIAG * 3.0, Xref[0], Uref[0])
+        got = nlp.get_cost()
+        assert got.shape == want.shape and np.array_equal(got, want)
+        ref = HybridNLP(batch.model, want, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+        assert np.array_equal(nlp.eval_f(Z).cpu().numpy(), ref.eval_f(Z).cpu().numpy())
+        assert np.array_equal(nlp.grad_f(Z).cpu().numpy(), ref.grad_f(Z).cpu().numpy())
