@@ -7,7 +7,10 @@ inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2]
 k_trans=14, FP64): the HBM-bound regime the metric's roofline half is quoted on; configs[1]
 (B=1024, launch-latency regime) is timed beside it and reported under "other".
 Multi-GPU: weak scaling, one process per GPU, the shard is generated locally, no data-path
-collective; one RCCL gather of (f, c) to rank 0 after the K steps, inside the timed region.
+collective; one RCCL gather of the per-problem results (objective f, constraint violation) to rank 0
+after the K steps, inside the timed region ("gather f, c (or norms)").  The gather
+of the full constraint vectors (379 MB per rank) is timed once outside the region and reported as
+`gather_c_ms`; Jacobian values stay resident on the GPU that produced them.
 """
 import argparse
 import ctypes
@@ -127,7 +130,7 @@ def main():
     # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
     batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials)
     placement_ms = list(build.last_trials)
-    f = nlp.new_f()
+    f, viol = nlp.new_f(), nlp.new_f()
     K, W = args.steps, args.warmup
 
     multi = world > 1 or force_dist
@@ -140,8 +143,9 @@ def main():
     # warmup (untimed): W launches, one objective pass, and one gather so RCCL is initialised
     nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
     nlp.eval_f(Z, f)
+    nlp.constraint_violation(c, viol)
     if multi:
-        D.gather_results(f, c)
+        D.gather_results(f, viol)
     barrier()
 
     t0 = time.perf_counter()
@@ -151,13 +155,22 @@ def main():
         torch.cuda.synchronize()
         tg = time.perf_counter()
         nlp.eval_f(Z, f)
-        D.gather_results(f, c)  # the single end-of-job exchange (RCCL over xGMI)
+        nlp.constraint_violation(c, viol)
+        D.gather_results(f, viol)  # the single end-of-job exchange (RCCL over xGMI): per-problem results
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - tg
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
     t_gather = D.max_over_ranks(t_gather, dev)
+    t_gather_c = 0.0
+    if multi:  # for the record, outside the timed region: the full constraint vectors to rank 0
+        D.gather_to_root(c)
+        barrier()
+        tg = time.perf_counter()
+        D.gather_to_root(c)
+        torch.cuda.synchronize()
+        t_gather_c = D.max_over_ranks(time.perf_counter() - tg, dev)
 
     knots_per_step = batch.B * batch.N * world
     value = knots_per_step * K / elapsed
@@ -198,7 +211,8 @@ def main():
                            "launch_ms_min": float(np.min(ms_each)), "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N)}
         if multi:
-            out["gather_ms"] = t_gather * 1e3
+            out["gather_ms"] = t_gather * 1e3        # f + constraint violation, inside the timed region
+            out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank), outside it
         if world == 1 and not args.no_other and args.workload != "config2":
             b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank)
             ms2 = n2.time_c_and_jac(Z2, c2, v2, warmup=5, iters=50)

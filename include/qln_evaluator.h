@@ -128,6 +128,10 @@ int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, u
 /* The fused hot path: eval_c! and jac_c! of every knot of every problem in one launch. */
 int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags);
 int qln_jacobian_init_constants(qln_handle* h, double* vals);
+/* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
+ * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
+ * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */
+int qln_constraint_violation(qln_handle* h, const double* c, double* viol /*[B]*/);
 /* The step before the path: the notebook's initial guess Z0 = packZ(nlp, Xguess, Uref)
  * (src/main.ipynb:181-198, src/nlp.jl:94-102, src/ref_traj.jl:19-34) for every problem of the batch, written
  * on the device in the handle's Z layout.  Needs k_trans >= 2 for every problem (the notebook divides by

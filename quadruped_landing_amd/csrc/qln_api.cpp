@@ -412,6 +412,14 @@ int qln_jacobian_init_constants(qln_handle* h, double* vals) {
     return QLN_OK;
 }
 
+int qln_constraint_violation(qln_handle* h, const double* c, double* viol) {
+    if (int rc = check_handle(h)) return rc;
+    if (!c || !viol) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_constraint_violation: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_violation(h->p, c, viol, h->stream));
+    return QLN_OK;
+}
+
 int qln_initial_guess(qln_handle* h, double* Z) {
     if (int rc = check_handle(h)) return rc;
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");

@@ -37,6 +37,7 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream);
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream);
 hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t stream);
+hipError_t launch_constraint_violation(const BatchParams& p, const double* c, double* viol, hipStream_t stream);
 hipError_t launch_lqr_cost(const BatchParams& p, const double* qrqf, double dt, double* cost, int cost_batch,
                            hipStream_t stream);
 

@@ -690,6 +690,35 @@ __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __
     Z[(int64_t)b * P.z_stride + i] = v;
 }
 
+// Constraint violation per problem, as Ipopt reports it for the reference's solve (src/main.ipynb:712): the largest
+// violation of the bounds of src/nlp.jl:66-69 -- |c_i| over the equality rows, max(0, -c_i) over the clearance rows
+// (lb = 0, ub = +Inf).  One wave per problem; NaN anywhere in the problem's c gives NaN.
+__global__ __launch_bounds__(kWave) void k_constraint_violation(BatchParams P, const double* __restrict__ C,
+                                                               double* __restrict__ viol) {
+    const int lane = threadIdx.x;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;
+    const ProblemDesc pd = P.desc[b];
+    const int N = P.N;
+    const int m = 18 * N - pd.k_trans + 16;
+    const int m_eq = m - N;
+    const double* __restrict__ cb = C + pd.c_off;
+    double v = 0.0;
+    bool bad = false;
+    for (int i = lane; i < m; i += kWave) {
+        const double x = cb[i];
+        bad = bad || (x != x);
+        v = fmax(v, (i < m_eq) ? fabs(x) : fmax(-x, 0.0));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v = fmax(v, __shfl_xor(v, off, kWave));
+        const int other_bad = __shfl_xor((int)bad, off, kWave);  // unconditional: every lane must take part
+        bad = bad | (other_bad != 0);
+    }
+    if (lane == 0) viol[b] = bad ? __builtin_nan("") : v;
+}
+
 // LQR cost records of the notebook's objective (src/main.ipynb:158-161): obj[k] = LQRCost(Q, R, Xref[k], Uref[k])
 // for k < N, obj[N] = LQRCost(Qf, R*0, Xref[N], Uref[1]), with Xref/Uref of reference_trajectory
 // (src/ref_traj.jl:6-39) and LQRCost of src/quadratic_cost.jl:33-42, built on the device: one thread per
@@ -793,6 +822,11 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
     hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_constraint_violation(const BatchParams& p, const double* c, double* viol, hipStream_t stream) {
+    hipLaunchKernelGGL(k_constraint_violation, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, c, viol);
     return hipGetLastError();
 }
 

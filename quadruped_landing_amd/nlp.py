@@ -302,6 +302,13 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
         return vals
 
+    def constraint_violation(self, c, out=None):
+        """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
+        out = self.new_f() if out is None else out
+        _lib.check(_lib.lib().qln_constraint_violation(self._h, self._check(c, self.dims.c_total, "c"),
+                                                       self._check(out, self.B, "viol")))
+        return out
+
     def initial_guess(self, out=None):
         """Z0 of the notebook's initial-guess rule (src/main.ipynb:181-198) for every problem, on the device."""
         out = self.new_Z() if out is None else out

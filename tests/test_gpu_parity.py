@@ -329,3 +329,29 @@ def test_lqr_cost_built_on_device_is_bitwise_the_host_builder():
         ref = HybridNLP(batch.model, want, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
         assert np.array_equal(nlp.eval_f(Z).cpu().numpy(), ref.eval_f(Z).cpu().numpy())
         assert np.array_equal(nlp.grad_f(Z).cpu().numpy(), ref.grad_f(Z).cpu().numpy())
+
+
+def test_constraint_violation_reproduces_ipopts_figure(golden_dir):
+    """KA2 end to end on the GPU: eval_c + the violation reduction give the 'Constraint violation' Ipopt printed for
+    the shipped run (src/main.ipynb:712), digit for digit; ragged batches agree with a numpy reduction of the oracle's c."""
+    import os
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    nb = PG.notebook_problem()
+    nb.Z = np.loadtxt(os.path.join(golden_dir, "data_6.csv"))[None, :]
+    nlp = HybridNLP(nb.model, nb.obj, nb.init_mode, nb.k_trans, nb.N, nb.x0, nb.xf)
+    v = nlp.constraint_violation(nlp.eval_c(nlp.upload_Z(nb.Z)))
+    assert float(v[0]) == 1.4928675395736724e-06
+
+    batch = PG.make_batch(200, 30, seed=31, ragged=True)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    c = nlp.eval_c(nlp.upload_Z(batch.Z))
+    got = nlp.constraint_violation(c).cpu().numpy()
+    ref = oracle_batch(batch, nlp, want_j=False)["c"]
+    for b in range(batch.B):
+        cb = nlp.split_c(ref, b)
+        want = max(np.abs(cb[: cb.size - batch.N]).max(), np.maximum(-cb[cb.size - batch.N :], 0).max())
+        assert got[b] == want or abs(got[b] - want) <= 4e-16 * want  # clearance rows: device sin vs libm
+    c[nlp.c_off[5] + 40] = float("nan")
+    assert np.isnan(nlp.constraint_violation(c).cpu().numpy()[5])
