@@ -13,7 +13,7 @@
 // 1-KiB-per-instruction stores.  The kernel is HBM-write bound (2400 B of Jacobian per knot against
 // ~0.4 kflop), so everything is organised around that store stream.
 //
-// Closed form of the step (DESIGN.md "Step Jacobian"): with zero-order-hold forces every
+// Closed form of the step ("Jacobian phase"): with zero-order-hold forces every
 // acceleration except the body's angular one is constant over the step, so RK4 reproduces
 //   p+ = p + h v + h^2/2 a,  v+ = v + h a            (body, and the free foot; pinned foot: identity)
 //   w+ = w  + (h tau0 + h^2/2 tauv + h^3/6 taua)/Ib
