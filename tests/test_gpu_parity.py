@@ -355,3 +355,20 @@ def test_constraint_violation_reproduces_ipopts_figure(golden_dir):
         assert got[b] == want or abs(got[b] - want) <= 4e-16 * want  # clearance rows: device sin vs libm
     c[nlp.c_off[5] + 40] = float("nan")
     assert np.isnan(nlp.constraint_violation(c).cpu().numpy()[5])
+
+
+def test_random_shapes_and_layouts_property():
+    """Randomised shapes/layouts (hypothesis): any B, N, per-problem k_trans / init_mode, Z stride and offset alignment
+    gives oracle parity through the C ABI."""
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import problem_gen as PG
+
+    @settings(max_examples=20, deadline=None)
+    @given(B=st.integers(1, 40), N=st.integers(2, 150), pad=st.integers(0, 9), align=st.sampled_from([1, 2, 3, 16, 32]),
+           seed=st.integers(0, 10**6))
+    def check(B, N, pad, align, seed):
+        batch = PG.make_batch(B, N, seed=seed, ragged=True) if N > 3 else PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        out = _gpu_eval(batch, z_stride=(20 * N - 5 + pad) if pad else 0, align=align)
+        _compare(batch, *out)
+
+    check()
