@@ -121,6 +121,83 @@ __global__ __launch_bounds__(64) void k_fill_region_skew(double2* __restrict__ p
     for (int i = threadIdx.x; i < region2; i += 64) q[i] = v;
 }
 
+// B9: the evaluator's store structure (T=16 tile, XCD-contiguous) with a synthetic non-store phase in front of each
+// problem: a dependent 6.4-KB read plus DELAY x 64 clocks of s_sleep.  How much do the evaluator's load/compute
+// phases cost at 4 waves per CU if the store stream itself is unchanged?
+template <int DELAY>
+__global__ __launch_bounds__(64) void k_fill_tile_delay(double2* __restrict__ p, const double* __restrict__ src, int nknots,
+                                                        size_t stride2, int nregions) {
+    __shared__ double2 tile[16 * 150];
+    const int r = (blockIdx.x % 8) * (nregions / 8) + blockIdx.x / 8;
+    double acc = 0.0;
+    if (DELAY >= 0) {
+        const double* z = src + (size_t)r * 795;
+        for (int i = threadIdx.x; i < 795; i += 64) acc += z[i];
+        for (int d = 0; d < DELAY; ++d) __builtin_amdgcn_s_sleep(64);
+    }
+    for (int i = threadIdx.x; i < 16 * 150; i += 64) tile[i] = make_double2(1.0 + acc, 2.0);
+    __syncthreads();
+    double2* q = p + (size_t)r * stride2;
+    for (int k0 = 0; k0 < nknots; k0 += 16) {
+        const int np = min(16, nknots - k0) * 150;
+        double2* d = q + (size_t)k0 * 150;
+        for (int i = threadIdx.x; i < np; i += 64) d[i] = tile[i];
+    }
+}
+
+// B10: persistent waves with the NEXT problem's 6.4-KB read prefetched into registers while the current problem's
+// tile stream is stored (1024 single-wave blocks, XCD-contiguous ranges, 128 waves per XCD walking their range)
+template <bool PREFETCH, int LDMODE = 0>
+__global__ __launch_bounds__(64) void k_fill_tile_persistent(double2* __restrict__ p, const double* __restrict__ src, int nknots,
+                                                             size_t stride2, int nregions, int period = 0) {
+    __shared__ double2 tile[16 * 150];
+    const int per = nregions / 8, x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int lane = threadIdx.x;
+    double zr[13];
+    int r = x * per + slot;
+    auto issue = [&](int rr) {
+        const double* z = src + (size_t)rr * 795;
+#pragma unroll
+        for (int it = 0; it < 13; ++it) {
+            const double* a = z + min(it * 64 + lane, 794);
+            if (LDMODE == 0) zr[it] = *a;
+            if (LDMODE == 1) zr[it] = __builtin_nontemporal_load(a);
+            if (LDMODE == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(zr[it]) : "v"(a) : "memory");
+            if (LDMODE == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(zr[it]) : "v"(a) : "memory");
+        }
+        if (LDMODE >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // asm loads are not counted by hipcc
+    };
+    if (slot < per) issue(r);
+    for (int s = slot; s < per; s += nslots) {
+        r = x * per + s;
+        double acc = 0.0;
+#pragma unroll
+        for (int it = 0; it < 13; ++it) acc += zr[it];   // consume the staged read (waits for it)
+        for (int i = lane; i < 16 * 150; i += 64) tile[i] = make_double2(1.0 + acc, 2.0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (PREFETCH && s + nslots < per) {
+            if (period > 0) {
+                // time-division experiment: every wave of the chip issues its reads only in the first 1/8 of each
+                // `period` ticks of the 100-MHz real-time counter, so the DRAM channels see reads in bursts
+                int guard = 0;
+                while ((__builtin_amdgcn_s_memrealtime() % (unsigned long long)period) >= (unsigned long long)(period / 8) &&
+                       ++guard < 100000)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            issue(r + nslots);  // next problem's read flies under this problem's stores
+        }
+        double2* q = p + (size_t)r * stride2;
+        for (int k0 = 0; k0 < nknots; k0 += 16) {
+            const int np = min(16, nknots - k0) * 150;
+            double2* d = q + (size_t)k0 * 150;
+            for (int i = lane; i < np; i += 64) d[i] = tile[i];
+        }
+        if (!PREFETCH && s + nslots < per) issue(r + nslots);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -201,7 +278,31 @@ int main() {
         printf("tile-interleaved 512B G=128: %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         ms = time_ms([&] { k_fill_region_lds<16><<<B, 64>>>((double2*)buf, 39, stride / 2); });
         printf("fill_region_lds T=16 rr    : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
-        for (int skew : {0, 1, 37, 333, 1021, 4099}) {
+        ms = time_ms([&] { k_fill_tile_delay<-1><<<B, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 XCDc, no front phase       : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_delay<0><<<B, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 XCDc, 6.4 KB read in front : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_delay<2><<<B, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 XCDc, read + 8k clk idle   : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_delay<4><<<B, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 XCDc, read + 16k clk idle  : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_delay<8><<<B, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 XCDc, read + 32k clk idle  : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_persistent<false><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 persistent, read after stores : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_persistent<true><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 persistent, read prefetched   : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        for (int period : {200, 400, 800, 1600, 3200}) {
+            ms = time_ms([&] { k_fill_tile_persistent<true, 0><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B, period); });
+            printf("tile16 persistent, prefetched, read window every %4d x10ns : %.3f ms  %.1f GB/s\n", period, ms, (double)B * 39 * 2400 / ms / 1e6);
+        }
+        ms = time_ms([&] { k_fill_tile_persistent<true, 1><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 persistent, prefetched, nt loads : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_persistent<false, 2><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 persistent, sc1 loads (waited)   : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_tile_persistent<false, 3><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
+        printf("tile16 persistent, sc0 sc1 loads (wait) : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        for (int skew : {0}) {
             ms = time_ms([&] { k_fill_region_skew<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, B, skew); });
             printf("fill_region XCD-contig skew=%-5d: %.3f ms  %.1f GB/s\n", skew, ms, wbytes / ms / 1e6);
         }
