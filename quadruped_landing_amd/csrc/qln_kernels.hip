@@ -23,7 +23,9 @@
 // (src/planar_quadruped.jl:225-248) up to rounding.
 #include "qln_device.h"
 
+#ifdef QLN_TUNING
 #include <cstdlib>
+#endif
 
 namespace qln {
 
@@ -772,11 +774,15 @@ template <int T, int KC, int W>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
     dim3 grid(xcd_grid(nb)), block(kWave);
-    // experiment knob: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
+#ifdef QLN_TUNING
+    // tuning build only: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
         const char* e = getenv("QLN_PAD_LDS");
         return e ? (unsigned)atoi(e) : 0u;
     }();
+#else
+    constexpr unsigned pad = 0;
+#endif
     if (c && vals)
         hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
     else if (c)
@@ -800,7 +806,8 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
     if (nb <= 0 || (!c && !vals)) return hipSuccess;
     // Shipping configuration: T=16 (38.4 KB tile, 4 waves per CU, one per SIMD) when the Jacobian is
     // written, T=8 / 8 waves per CU for the constraint-only launch (profiles/r01_variants.txt).
-    // QLN_VARIANT (read once) selects other instantiations for A/B measurements.
+#ifdef QLN_TUNING
+    // tuning build only (make tuning -> libqln_hip_tuning.so): QLN_VARIANT selects other instantiations for A/B runs
     static const int variant = [] {
         const char* e = getenv("QLN_VARIANT");
         return e ? atoi(e) : 0;
@@ -809,10 +816,11 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 1: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 2: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
-        default:
-            if (!vals) return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
-            return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        default: break;
     }
+#endif
+    if (!vals) return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+    return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
 }
 
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream) {
