@@ -372,3 +372,30 @@ def test_random_shapes_and_layouts_property():
         _compare(batch, *out)
 
     check()
+
+
+def test_dense_host_jacobian_of_any_problem_in_a_batch_and_two_handles():
+    """MOI dense mode addresses one problem of a batch; two handles on the same device do not interfere."""
+    from oracle import oracle as O
+    from quadruped_landing_amd import HybridNLP, moi, problem_gen as PG
+    from tests.helpers import oracle_model
+
+    batch = PG.make_batch(5, 18, seed=41, ragged=True)
+    other = PG.make_batch(7, 25, seed=42, ragged=True)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    nlp2 = HybridNLP(other.model, other.obj, other.init_mode, other.k_trans, other.N, other.x0, other.xf)
+    for b in (0, 2, 4):
+        m_nlp, n_nlp = nlp.num_duals(b), nlp.num_primals()
+        vec = np.full(m_nlp * n_nlp, np.nan)
+        _ = nlp2.eval_c_host(other.Z)  # interleave work on the other handle
+        moi.eval_constraint_jacobian(nlp, vec, batch.Z[b], b)
+        D = vec.reshape((m_nlp, n_nlp), order="F")
+        o = O.OracleNLP(batch.N, int(batch.k_trans[b]), int(batch.init_mode[b]), batch.x0[b], batch.xf[b], batch.obj[b],
+                        oracle_model(batch.model))
+        Dref = o.jac_c_dense(batch.Z[b])
+        assert np.array_equal(np.isnan(D), np.isnan(Dref))
+        assert rel_err(D, Dref, floor=1e-300) <= RTOL
+    c2 = nlp2.eval_c_host(other.Z)
+    ref2 = oracle_batch(other, nlp2, want_j=False)["c"]
+    ok = ~np.isnan(ref2)
+    assert rel_err(c2[ok], ref2[ok], floor=1.0) <= RTOL
