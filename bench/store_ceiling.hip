@@ -198,6 +198,25 @@ __global__ __launch_bounds__(64) void k_fill_tile_persistent(double2* __restrict
     }
 }
 
+// B11: the north star's literal mapping, store side only: ONE WAVE PER KNOT POINT, each wave writes its 2400-B block
+// (150 x 16 B: two full wave instructions + 22 lanes), blocks of a problem contiguous.  No arithmetic, no reads.
+__global__ __launch_bounds__(64) void k_fill_wave_per_knot(double2* __restrict__ p, int nknots, size_t stride2, int nregions) {
+    const double2 v = make_double2(1.0, 2.0);
+    const int g = blockIdx.x;                       // flat knot index, problem-major
+    const int r = g / nknots, k = g - r * nknots;
+    double2* q = p + (size_t)r * stride2 + (size_t)k * 150;
+    for (int i = threadIdx.x; i < 150; i += 64) q[i] = v;
+}
+// same, 4 knots (waves) per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_fill_wave_per_knot4(double2* __restrict__ p, int nknots, size_t stride2, int nregions) {
+    const double2 v = make_double2(1.0, 2.0);
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nknots * nregions) return;
+    const int r = g / nknots, k = g - r * nknots;
+    double2* q = p + (size_t)r * stride2 + (size_t)k * 150;
+    for (int i = threadIdx.x & 63; i < 150; i += 64) q[i] = v;
+}
+
 // C: copy with 8 B/lane loads and stores (calibration of FETCH_SIZE for the Z staging loads)
 __global__ void k_copy8(const double* __restrict__ a, double* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -302,6 +321,10 @@ int main() {
         printf("tile16 persistent, sc1 loads (waited)   : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         ms = time_ms([&] { k_fill_tile_persistent<false, 3><<<1024, 64>>>((double2*)buf, src, 39, stride / 2, B); });
         printf("tile16 persistent, sc0 sc1 loads (wait) : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_wave_per_knot<<<B * 39, 64>>>((double2*)buf, 39, stride / 2, B); });
+        printf("wave per knot (2.56M single-wave workgroups)  : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
+        ms = time_ms([&] { k_fill_wave_per_knot4<<<(B * 39 + 3) / 4, 256>>>((double2*)buf, 39, stride / 2, B); });
+        printf("wave per knot, 4 waves per workgroup          : %.3f ms  %.1f GB/s\n", ms, (double)B * 39 * 2400 / ms / 1e6);
         for (int skew : {0}) {
             ms = time_ms([&] { k_fill_region_skew<<<B, 64>>>((double2*)buf, (int)(region / 2), stride / 2, B, skew); });
             printf("fill_region XCD-contig skew=%-5d: %.3f ms  %.1f GB/s\n", skew, ms, wbytes / ms / 1e6);
