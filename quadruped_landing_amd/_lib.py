@@ -104,6 +104,15 @@ def lib() -> C.CDLL:
     """Load libqln_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and not os.environ.get("QLN_LIB_PATH"):
+            # a source checkout without the built artefact: compile it in-tree once (hipcc cross-compiles gfx950
+            # without a GPU); anything else is an error -- there is no CPU fallback
+            import shutil
+            import subprocess
+
+            csrc = os.path.join(_HERE, "csrc")
+            if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+                subprocess.call(["make", "-C", csrc, "libqln_hip.so"], stdout=subprocess.DEVNULL)
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C quadruped_landing_amd/csrc` "
