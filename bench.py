@@ -216,8 +216,13 @@ def main():
         if world == 1 and not args.no_other and args.workload != "config2":
             b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank)
             ms2 = n2.time_c_and_jac(Z2, c2, v2, warmup=5, iters=50)
+            alg2 = float(np.sum(algorithmic_bytes(b2.N, b2.k_trans)))
             out["other"] = {"config2_B1024_N40": {"launch_ms_avg": float(np.mean(ms2)),
-                                                   "knot_evals_per_s": b2.B * b2.N / (float(np.mean(ms2)) * 1e-3)}}
+                                                   "knot_evals_per_s": b2.B * b2.N / (float(np.mean(ms2)) * 1e-3),
+                                                   "achieved_GBs": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9,
+                                                   "roofline_frac": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "note": "BASELINE.json configs[1]: one wave per problem = 4 waves per CU, "
+                                                           "a single round: launch-latency regime"}}
             del b2, n2, Z2, c2, v2
         if world == 1 and not args.no_cpu_baseline:
             one, allc = cpu_baseline(batch, nlp)
