@@ -3,9 +3,10 @@
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 A step = one launch of eval_c! + jac_c! over every knot of every problem of the rank's shard, with
-inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2] (B=65536, N=40,
-k_trans=14, FP64): the HBM-bound regime the metric's roofline half is quoted on; configs[1]
-(B=1024, launch-latency regime) is timed beside it and reported under "other".
+inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2] (0-based: B=65536, N=40,
+k_trans=14, FP64 -- "config 3" of BASELINE.md): the HBM-bound regime the metric's roofline half is quoted on;
+configs[1] (B=1024, launch-latency regime) is timed beside it and reported under "other".  The --workload names
+config2/config3/config4 follow BASELINE.md's 1-based table, i.e. configs[1]/[2]/[3].
 Multi-GPU: weak scaling, one process per GPU, the shard is generated locally, no data-path
 collective; one RCCL gather of the per-problem results (objective f, constraint violation) to rank 0
 after the K steps, inside the timed region ("gather f, c (or norms)").  The gather
@@ -199,7 +200,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1])}]: {WORKLOADS[args.workload]['desc']}; "
+        "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] (0-based; 'config {args.workload[-1]}' of BASELINE.md): {WORKLOADS[args.workload]['desc']}; "
                                "per-rank shard, constants of the Jacobian pre-written",
                    "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride),
                    "placement_trials_ms": placement_ms},
@@ -221,7 +222,7 @@ def main():
                                                    "knot_evals_per_s": b2.B * b2.N / (float(np.mean(ms2)) * 1e-3),
                                                    "achieved_GBs": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9,
                                                    "roofline_frac": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                   "note": "BASELINE.json configs[1]: one wave per problem = 4 waves per CU, "
+                                                   "note": "BASELINE.json configs[1] (0-based): one wave per problem = 4 waves per CU, "
                                                            "a single round: launch-latency regime"}}
             del b2, n2, Z2, c2, v2
         if world == 1 and not args.no_cpu_baseline:
