@@ -40,7 +40,22 @@ def algorithmic_bytes(N, k_trans):
     return 8 * (20 * N - 5) + 8 * (18 * N - k_trans + 16) + 8 * (300 * (N - 1) + N)
 
 
-def build(workload, seed, device, placement_trials=1):
+NNZ_CONTACT, NNZ_FLIGHT, NNZ_JUMP = 71, 57, 56  # structural non-zeros of a 15x20 step block
+
+
+def strict_bytes(N, k_trans):
+    """SURVEY.md 8d "strict (structural-nnz) variant": as algorithmic_bytes, but only the structurally non-zero
+    entries of every step block count: 71 in contact modes 1/2, 57 in mode 3, and 56 at the jump knot k_trans-1
+    (71 minus the 15 entries in the rows the jump mask zeroes: 5, 7, 11-15)."""
+    kt = np.asarray(k_trans, dtype=np.int64)
+    n_contact = np.clip(kt - 2, 0, N - 1)                       # knots k < k_trans-1
+    n_jump = ((kt - 1 >= 1) & (kt - 1 <= N - 1)).astype(np.int64)
+    n_flight = np.clip(N - kt, 0, N - 1)                        # knots k_trans <= k <= N-1
+    nnz = NNZ_CONTACT * n_contact + NNZ_JUMP * n_jump + NNZ_FLIGHT * n_flight
+    return 8 * (20 * N - 5) + 8 * (18 * N - kt + 16) + 8 * (nnz + N)
+
+
+def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks"):
     import torch
     from quadruped_landing_amd import HybridNLP, problem_gen as PG
 
@@ -48,7 +63,7 @@ def build(workload, seed, device, placement_trials=1):
     # per-problem cost tables (config 4: 1.7 GB) are built on the device (qln_set_lqr_cost), not uploaded
     batch = PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=seed, ragged=w["ragged"], build_obj=not w["ragged"])
     nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
-                    device=device, stream=torch.cuda.current_stream())
+                    device=device, stream=torch.cuda.current_stream(), jac_format=jac_format)
     if batch.obj is None:
         nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=True)
     Z = nlp.upload_Z(batch.Z)
@@ -107,6 +122,9 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other", action="store_true")
+    ap.add_argument("--jac-format", default="dense_blocks", choices=["dense_blocks", "structural"],
+                    help="layout of the step blocks in vals: the reference's dense 15x20 blocks (the unit SURVEY.md 8d "
+                         "prices) or only their structurally non-zero entries (priced at the strict byte count)")
     ap.add_argument("--placement-trials", type=int, default=4,
                     help="candidate allocations of the Jacobian buffer tried at setup (1 = take the first)")
     args = ap.parse_args()
@@ -129,7 +147,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
-    batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials)
+    batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
+                                   jac_format=args.jac_format)
     placement_ms = list(build.last_trials)
     f, viol = nlp.new_f(), nlp.new_f()
     K, W = args.steps, args.warmup
@@ -176,14 +195,19 @@ def main():
     knots_per_step = batch.B * batch.N * world
     value = knots_per_step * K / elapsed
 
-    alg_bytes = float(np.sum(algorithmic_bytes(batch.N, batch.k_trans)))
+    structural = args.jac_format == "structural"
+    # the bytes a launch must move: dense 15x20 blocks or, when only the structural non-zeros are
+    # written, 8d's strict figure
+    alg_bytes = float(np.sum((strict_bytes if structural else algorithmic_bytes)(batch.N, batch.k_trans)))
     avg_ms = float(np.mean(ms_each))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    strict = float(np.sum(strict_bytes(batch.N, batch.k_trans)))
+    strict_achieved = strict / (avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(args.workload + ("_structural" if structural else ""), {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -202,7 +226,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] (0-based; 'config {args.workload[-1]}' of BASELINE.md): {WORKLOADS[args.workload]['desc']}; "
                                "per-rank shard, constants of the Jacobian pre-written",
-                   "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride),
+                   "jac_format": args.jac_format, "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride),
                    "placement_trials_ms": placement_ms},
     }
     if rank == 0:
@@ -210,20 +234,37 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms,
                            "launch_ms_min": float(np.min(ms_each)), "algorithmic_bytes_per_launch": alg_bytes,
-                           "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N)}
+                           "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N),
+                           # the output format is the dense 15x20 block, so the figure that counts only
+                           # structurally non-zero entries is quoted beside it
+                           "strict_nnz": {"bytes_per_knot_eval": strict / (batch.B * batch.N), "achieved": strict_achieved,
+                                          "frac": strict_achieved / HBM_PEAK_GBS}}
         if multi:
             out["gather_ms"] = t_gather * 1e3        # f + constraint violation, inside the timed region
             out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank), outside it
+        if world == 1 and not args.no_other and not structural:
+            # same workload, structural format (only the non-zeros of every step block are written)
+            del vals
+            bs, ns, Zs, cs, vs = build(args.workload, seed=rank, device=local_rank, placement_trials=1, jac_format="structural")
+            mss = ns.time_c_and_jac(Zs, cs, vs, warmup=5, iters=K)
+            sb = float(np.sum(strict_bytes(bs.N, bs.k_trans)))
+            out.setdefault("other", {})["structural_format"] = {
+                "launch_ms_avg": float(np.mean(mss)), "knot_evals_per_s": bs.B * bs.N / (float(np.mean(mss)) * 1e-3),
+                "bytes_per_knot_eval": sb / (bs.B * bs.N), "achieved_GBs": sb / (float(np.mean(mss)) * 1e-3) / 1e9,
+                "roofline_frac": sb / (float(np.mean(mss)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "jac_format=structural (QLN_JAC_FORMAT_STRUCTURAL): 71/56/57 values per step block instead of "
+                        "300; priced at SURVEY.md 8d's strict byte count"}
+            del bs, ns, Zs, cs, vs
         if world == 1 and not args.no_other and args.workload != "config2":
-            b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank)
+            b2, n2, Z2, c2, v2 = build("config2", seed=0, device=local_rank, jac_format=args.jac_format)
             ms2 = n2.time_c_and_jac(Z2, c2, v2, warmup=5, iters=50)
-            alg2 = float(np.sum(algorithmic_bytes(b2.N, b2.k_trans)))
-            out["other"] = {"config2_B1024_N40": {"launch_ms_avg": float(np.mean(ms2)),
+            alg2 = float(np.sum((strict_bytes if structural else algorithmic_bytes)(b2.N, b2.k_trans)))
+            out.setdefault("other", {})["config2_B1024_N40"] = {"launch_ms_avg": float(np.mean(ms2)),
                                                    "knot_evals_per_s": b2.B * b2.N / (float(np.mean(ms2)) * 1e-3),
                                                    "achieved_GBs": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9,
                                                    "roofline_frac": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                    "note": "BASELINE.json configs[1] (0-based): one wave per problem = 4 waves per CU, "
-                                                           "a single round: launch-latency regime"}}
+                                                           "a single round: launch-latency regime"}
             del b2, n2, Z2, c2, v2
         if world == 1 and not args.no_cpu_baseline:
             one, allc = cpu_baseline(batch, nlp)

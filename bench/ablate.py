@@ -15,7 +15,8 @@ def t_ms(fn, iters=20):
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "config3"
-batch, nlp, Z, c, vals = build(wl, 0, 0)
+fmt = sys.argv[2] if len(sys.argv) > 2 else "dense_blocks"
+batch, nlp, Z, c, vals = build(wl, 0, 0, jac_format=fmt)
 f = nlp.new_f(); g = nlp.new_Z()
 print(wl, "fused c+J      : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=False)))
 print(wl, "fused +consts  : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=True)))

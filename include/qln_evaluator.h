@@ -37,6 +37,13 @@
  *         The first 300(N-1)+N values depend on Z; the rest are constants and are
  *         written only when QLN_JAC_WRITE_CONSTANTS is set (or once by
  *         qln_jacobian_init_constants).
+ *         With jac_format = QLN_JAC_FORMAT_STRUCTURAL only the first section differs: a step block holds
+ *         just the entries that can be non-zero in the knot's contact mode, in column-major order of
+ *         that pattern -- 71 values in contact modes 1/2, 56 at the transition knot k_trans-1 (the jump
+ *         mask zeroes rows 5, 7, 11-15, src/planar_quadruped.jl:262-263), 57 in mode 3 -- so the section
+ *         has 71*n1 + 56*nj + 57*n3 values (n1 = knots before the transition knot, nj = 0/1, n3 = knots
+ *         from k_trans on).  Entries left out are exactly 0.0 in the reference's ForwardDiff Jacobian for
+ *         every Z; qln_jacobian_structure lists the entries that remain.
  *   grad  same layout as Z.        f: one double per problem.
  */
 #ifndef QLN_EVALUATOR_H
@@ -62,6 +69,10 @@ extern "C" {
 /* flags for the Jacobian entry points */
 #define QLN_JAC_WRITE_CONSTANTS 1u
 
+/* qln_batch_desc.jac_format: layout of the step-block section of vals (see "Layouts") */
+#define QLN_JAC_FORMAT_DENSE_BLOCKS 0 /* one dense 15x20 block per dynamics knot: the reference's unit of work */
+#define QLN_JAC_FORMAT_STRUCTURAL 1   /* only the structurally non-zero entries of every block */
+
 typedef struct qln_handle qln_handle;
 
 /* PlanarQuadruped (src/planar_quadruped.jl:11-20) */
@@ -86,6 +97,7 @@ typedef struct qln_batch_desc {
     int64_t z_stride;         /* doubles between consecutive problems in Z/grad; 0 -> n_nlp (dense) */
     int32_t align;            /* c_off/j_off are rounded up to a multiple of this many doubles;
                                  0 -> 16 (128 B).  j_off is always kept even. */
+    int32_t jac_format;       /* QLN_JAC_FORMAT_* */
 } qln_batch_desc;
 
 typedef struct qln_dims {
@@ -93,7 +105,8 @@ typedef struct qln_dims {
     int32_t n_nlp;        /* 20N-5                           (src/nlp.jl:86) */
     int32_t m_nlp_max;    /* max_b 18N - k_trans(b) + 16     (src/nlp.jl:87) */
     int32_t nnz_max;      /* max_b nnz(b) */
-    int32_t nnz_dynamic;  /* 300(N-1)+N state-dependent values per problem */
+    int32_t nnz_dynamic;  /* state-dependent values at the head of a problem's vals segment: 300(N-1)+N with dense
+                             blocks; the largest per-problem count of the batch in the structural format */
     int64_t z_stride;
     int64_t z_total;      /* doubles to allocate for Z / grad */
     int64_t c_total;      /* doubles to allocate for c */
@@ -114,6 +127,8 @@ int qln_synchronize(qln_handle* h);
 int qln_get_dims(const qln_handle* h, qln_dims* out);
 int qln_get_offsets(const qln_handle* h, int64_t* c_off /*[B]*/, int64_t* j_off /*[B]*/);
 int qln_problem_dims(const qln_handle* h, int32_t b, int32_t* m_nlp, int32_t* nnz);
+/* number of state-dependent values at the head of problem b's vals segment (step blocks + N clearance entries) */
+int qln_problem_nnz_dynamic(const qln_handle* h, int32_t b, int32_t* nnz_dynamic);
 int qln_constraint_index_ranges(const qln_handle* h, int32_t b, int32_t cinds[14]); /* 1-based [start,end] x 7 */
 int qln_constraint_bounds(const qln_handle* h, int32_t b, double* lb, double* ub);
 /* 0-based (row, col) of every entry of problem b's vals segment (MOI.jacobian_structure, src/moi.jl:31-33,

@@ -18,6 +18,8 @@ QLN_ERR_HIP = -2
 QLN_ERR_NO_DEVICE = -3
 QLN_ERR_UNSUPPORTED = -4
 QLN_JAC_WRITE_CONSTANTS = 1
+QLN_JAC_FORMAT_DENSE_BLOCKS = 0
+QLN_JAC_FORMAT_STRUCTURAL = 1
 
 NX, NU, NZ, COST_STRIDE = 15, 5, 20, 41
 
@@ -39,6 +41,7 @@ class QlnBatchDesc(C.Structure):
         ("cost_batch", C.c_int32),
         ("z_stride", C.c_int64),
         ("align", C.c_int32),
+        ("jac_format", C.c_int32),
     ]
 
 
@@ -78,6 +81,7 @@ SIGNATURES = {
     "qln_get_dims": (C.c_int, [_vp, C.POINTER(QlnDims)]),
     "qln_get_offsets": (C.c_int, [_vp, _i64p, _i64p]),
     "qln_problem_dims": (C.c_int, [_vp, C.c_int32, _i32p, _i32p]),
+    "qln_problem_nnz_dynamic": (C.c_int, [_vp, C.c_int32, _i32p]),
     "qln_constraint_index_ranges": (C.c_int, [_vp, C.c_int32, _i32p]),
     "qln_constraint_bounds": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "qln_jacobian_structure": (C.c_int, [_vp, C.c_int32, _i32p, _i32p]),

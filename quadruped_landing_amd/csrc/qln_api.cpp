@@ -37,8 +37,10 @@ int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // sizes of src/nlp.jl:48-87
 int32_t m_nlp_of(int32_t N, int32_t kt) { return 18 * N - kt + 16; }
-int32_t nnz_dyn_of(int32_t N) { return 300 * (N - 1) + N; }
-int32_t nnz_of(int32_t N, int32_t kt) { return nnz_dyn_of(N) + 435 + 15 * (N - 1) + 3 * N - kt + 3; }
+int32_t nnz_dyn_of(int32_t N, int32_t kt, int32_t fmt) {
+    return (fmt == QLN_JAC_FORMAT_STRUCTURAL ? qln::step_block_offset(N - 1, N, kt) : 300 * (N - 1)) + N;
+}
+int32_t nnz_of(int32_t N, int32_t kt, int32_t fmt) { return nnz_dyn_of(N, kt, fmt) + 435 + 15 * (N - 1) + 3 * N - kt + 3; }
 
 void cinds_of(int32_t N, int32_t kt, int32_t out[14]) {
     int32_t e = 0;
@@ -119,6 +121,9 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     if (z_stride < n_nlp) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: z_stride < n_nlp");
     int64_t align = d->align ? d->align : 16;
     if (align < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: align must be >= 1");
+    const int32_t fmt = d->jac_format;
+    if (fmt != QLN_JAC_FORMAT_DENSE_BLOCKS && fmt != QLN_JAC_FORMAT_STRUCTURAL)
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: unknown jac_format");
     for (int32_t b = 0; b < d->B; ++b) {
         if (d->k_trans[b] < 1 || d->k_trans[b] > d->N + 1)
             return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: k_trans out of range [1, N+1] at problem " + std::to_string(b));
@@ -139,9 +144,10 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     h->j_off.resize(d->B);
     const int64_t jalign = (align % 2) ? align * 2 : align;  // keep j_off even: 16-byte stores
     int64_t co = 0, jo = 0;
-    int32_t m_max = 0, nnz_max = 0;
+    int32_t m_max = 0, nnz_max = 0, dyn_max = 0;
     for (int32_t b = 0; b < d->B; ++b) {
-        const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b]);
+        const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b], fmt);
+        dyn_max = std::max(dyn_max, nnz_dyn_of(d->N, d->k_trans[b], fmt));
         co = round_up(co, align);
         jo = round_up(jo, jalign);
         h->c_off[b] = co;
@@ -157,7 +163,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     D.n_nlp = n_nlp;
     D.m_nlp_max = m_max;
     D.nnz_max = nnz_max;
-    D.nnz_dynamic = nnz_dyn_of(d->N);
+    D.nnz_dynamic = dyn_max;
     D.z_stride = z_stride;
     D.z_total = z_stride * (int64_t)d->B;
     D.c_total = co;
@@ -199,6 +205,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     P.cost = h->d_cost;
     P.cost_batch = d->cost_batch;
     P.z_stride = z_stride;
+    P.jac_format = fmt;
     *out = h;
     return QLN_OK;
 }
@@ -249,7 +256,14 @@ static int check_problem(const qln_handle* h, int32_t b) {
 int qln_problem_dims(const qln_handle* h, int32_t b, int32_t* m_nlp, int32_t* nnz) {
     if (int rc = check_problem(h, b)) return rc;
     if (m_nlp) *m_nlp = m_nlp_of(h->dims.N, h->k_trans[b]);
-    if (nnz) *nnz = nnz_of(h->dims.N, h->k_trans[b]);
+    if (nnz) *nnz = nnz_of(h->dims.N, h->k_trans[b], h->p.jac_format);
+    return QLN_OK;
+}
+
+int qln_problem_nnz_dynamic(const qln_handle* h, int32_t b, int32_t* nnz_dynamic) {
+    if (int rc = check_problem(h, b)) return rc;
+    if (!nnz_dynamic) return fail(QLN_ERR_INVALID_ARGUMENT, "null nnz_dynamic");
+    *nnz_dynamic = nnz_dyn_of(h->dims.N, h->k_trans[b], h->p.jac_format);
     return QLN_OK;
 }
 
@@ -289,9 +303,13 @@ int qln_jacobian_structure(const qln_handle* h, int32_t b, int32_t* rows, int32_
         cols[e] = c;
         ++e;
     };
-    for (int32_t k = 0; k < N - 1; ++k)  // D[ci, [xi[k]; ui[k]]], src/constraints.jl:186-198
+    const bool structural = (h->p.jac_format == QLN_JAC_FORMAT_STRUCTURAL);
+    for (int32_t k = 0; k < N - 1; ++k) {  // D[ci, [xi[k]; ui[k]]], src/constraints.jl:186-198
+        const int cat = qln::step_category(k + 1, kt, im);
         for (int32_t c = 0; c < 20; ++c)
-            for (int32_t r = 0; r < 15; ++r) put(r_dyn + 15 * k + r, 20 * k + c);
+            for (int32_t r = 0; r < 15; ++r)
+                if (!structural || qln::step_entry_present(cat, r, c)) put(r_dyn + 15 * k + r, 20 * k + c);
+    }
     for (int32_t k = 0; k < N; ++k) put(r_bp + k, 20 * k + 2);       // :269-273
     for (int32_t c = 0; c < 15; ++c)                                  // :228
         for (int32_t r = 0; r < 15; ++r) put(r_init + r, c);
@@ -500,7 +518,7 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
     if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
     const int32_t N = h->dims.N, kt = h->k_trans[b];
-    const int32_t nnz = nnz_of(N, kt);
+    const int32_t nnz = nnz_of(N, kt, h->p.jac_format);
     const int64_t m = m_nlp_of(N, kt);
     h->h_vals_one.resize(nnz);
     QLN_HIP(hipMemcpyAsync(h->s_Z + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double), hipMemcpyHostToDevice,
@@ -518,6 +536,11 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
         for (int32_t c = 0; c < 15; ++c)
             for (int32_t r = 0; r < 15; ++r)
                 if (r != c) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * (k + 1) + c)] = 0.0;
+    if (h->p.jac_format == QLN_JAC_FORMAT_STRUCTURAL)
+        // D[ci, [xi[k]; ui[k]]] .= J assigns the whole 15x20 block: the entries the structural format leaves out are 0
+        for (int32_t k = 0; k < N - 1; ++k)
+            for (int32_t c = 0; c < 20; ++c)
+                for (int32_t r = 0; r < 15; ++r) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * k + c)] = 0.0;
     const double* v = h->h_vals_one.data();
     for (int32_t e = 0; e < nnz; ++e) jac[rows[e] + m * (int64_t)cols[e]] = v[e];
     return QLN_OK;

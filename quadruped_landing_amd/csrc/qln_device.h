@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/qln_evaluator.h"
+
 namespace qln {
 
 // Per-problem descriptor, one 32-byte record per problem so that a wave fetches everything it needs to
@@ -28,7 +30,79 @@ struct BatchParams {
     const double* cost;        // [cost_batch][N][41]
     int32_t cost_batch;
     int64_t z_stride;
+    int32_t jac_format;        // QLN_JAC_FORMAT_*: layout of the step-block section of vals
 };
+
+// ---------------------------------------------------------------------------------------------
+// Structural non-zeros of the 15x20 step Jacobian d(x+)/d[x;u] (contact*_jacobian,
+// src/planar_quadruped.jl:225-248, times the jump mask of :262-263 at the transition knot).
+// A knot falls into one of five categories; the pattern of each is fixed:
+//   0  contact mode 1 (foot 1 pinned, foot 2 free)   71 entries
+//   1  contact mode 2 (foot 2 pinned, foot 1 free)   71
+//   2  mode 3 (both feet pinned)                      57
+//   3  mode 1 followed by the jump map                56   (rows 5, 7, 11-15 masked; quirk Q1)
+//   4  mode 2 followed by the jump map                56
+// In QLN_JAC_FORMAT_STRUCTURAL the values of a block are stored in column-major order of its pattern.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStepCategories = 5;
+
+__host__ __device__ constexpr bool step_entry_present(int cat, int row, int col) {
+    const bool f1 = (cat == 1 || cat == 4);  // foot 1 free
+    const bool f2 = (cat == 0 || cat == 3);  // foot 2 free
+    const bool keep = cat < 3;               // not masked by the jump
+    switch (row) {
+        case 0: return col == 0 || col == 7 || col == 15 || col == 17 || col == 19;
+        case 1: return col == 1 || col == 8 || col == 16 || col == 18 || col == 19;
+        case 2:   // theta: every position, velocity, force and h
+        case 9:   // omega: the same without theta itself
+            if (col == 14) return false;
+            if (col == 2) return row == 2;
+            if (col == 10 || col == 11) return f1;
+            if (col == 12 || col == 13) return f2;
+            return true;
+        case 3: return col == 3 || (f1 && (col == 10 || col == 15 || col == 19));
+        case 4: return keep && (col == 4 || (f1 && (col == 11 || col == 16 || col == 19)));
+        case 5: return col == 5 || (f2 && (col == 12 || col == 17 || col == 19));
+        case 6: return keep && (col == 6 || (f2 && (col == 13 || col == 18 || col == 19)));
+        case 7: return col == 7 || col == 15 || col == 17 || col == 19;
+        case 8: return col == 8 || col == 16 || col == 18 || col == 19;
+        case 10: return keep && (col == 10 || (f1 && (col == 15 || col == 19)));
+        case 11: return keep && (col == 11 || (f1 && (col == 16 || col == 19)));
+        case 12: return keep && (col == 12 || (f2 && (col == 17 || col == 19)));
+        case 13: return keep && (col == 13 || (f2 && (col == 18 || col == 19)));
+        case 14: return keep && (col == 14 || col == 19);
+        default: return false;
+    }
+}
+
+// position of (row, col) inside the category's value list (column-major over the pattern)
+__host__ __device__ constexpr int step_entry_pos(int cat, int row, int col) {
+    int n = 0;
+    for (int c = 0; c <= col; ++c)
+        for (int r = 0; r < 15; ++r) {
+            if (c == col && r == row) return n;
+            if (step_entry_present(cat, r, c)) ++n;
+        }
+    return n;
+}
+
+__host__ __device__ constexpr int step_nnz(int cat) { return step_entry_pos(cat, 15, 19); }
+static_assert(step_nnz(0) == 71 && step_nnz(1) == 71 && step_nnz(2) == 57 && step_nnz(3) == 56 && step_nnz(4) == 56,
+              "structural non-zero counts of SURVEY.md 8.0");
+
+// Category of dynamics knot K (1-based, 1..N-1) under the mode schedule of src/constraints.jl:23-37.
+__host__ __device__ constexpr int step_category(int K, int k_trans, int init_mode) {
+    return (K == k_trans - 1) ? (init_mode == 1 ? 3 : 4) : (K < k_trans - 1) ? (init_mode == 1 ? 0 : 1) : 2;
+}
+
+// Offset (doubles) of 0-based knot k's block inside the step-block section of a problem, structural format:
+// contact knots first (71 each), then the jump knot (56), then mode 3 (57 each).  step_block_offset(N-1) is the
+// section's length.
+__host__ __device__ constexpr int step_block_offset(int k, int N, int k_trans) {
+    const int nc = (k_trans - 2 < 0) ? 0 : (k_trans - 2 > N - 1 ? N - 1 : k_trans - 2);  // knots before the jump
+    const int nj = (k_trans >= 2 && k_trans <= N) ? 1 : 0;
+    return (k <= nc) ? 71 * k : 71 * nc + 56 * nj + 57 * (k - nc - nj);
+}
 
 // Fused eval_c! + jac_c! over problems [b_begin, b_begin + nb).  c or vals may be null.
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,

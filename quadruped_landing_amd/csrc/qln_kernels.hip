@@ -23,6 +23,8 @@
 // (src/planar_quadruped.jl:225-248) up to rounding.
 #include "qln_device.h"
 
+#include <type_traits>
+
 #ifdef QLN_TUNING
 #include <cstdlib>
 #endif
@@ -181,6 +183,40 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
     }
 }
 
+// The 85 entries of the union pattern of a step block, as JW(row, col, value) statements over the
+// base quantities of the Jacobian phase (closed form in the file header): column 19 (d/dh, dense), row 2
+// (theta) and row 9 (omega), rows 0-1 (body position), rows 3-6 (foot positions; the y rows are masked at
+// the jump), rows 7-8 (body velocity), rows 10-13 (foot velocities) and row 14 (clock), masked at the jump
+// (quirk Q1).  The statements are in column-major order of (row, col) -- the order of the values inside a block
+// in both formats; the structural format's emission relies on it.
+#define QLN_STEP_ENTRIES()                                                                                        \
+    /* columns 0-6: positions */                                                                                  \
+    JW(0, 0, 1.0); JW(2, 0, -wAt * sFy); JW(9, 0, -wAw * sFy);                                                    \
+    JW(1, 1, 1.0); JW(2, 1, wAt * sFx); JW(9, 1, wAw * sFx);                                                      \
+    JW(2, 2, 1.0);                                                                                                \
+    JW(2, 3, wAt * F1y); JW(3, 3, 1.0); JW(9, 3, wAw * F1y);                                                      \
+    JW(2, 4, -wAt * F1x); JW(4, 4, keep); JW(9, 4, -wAw * F1x);                                                   \
+    JW(2, 5, wAt * F2y); JW(5, 5, 1.0); JW(9, 5, wAw * F2y);                                                      \
+    JW(2, 6, -wAt * F2x); JW(6, 6, keep); JW(9, 6, -wAw * F2x);                                                   \
+    /* columns 7-14: velocities and the clock */                                                                  \
+    JW(0, 7, h); JW(2, 7, -wBt * sFy); JW(7, 7, 1.0); JW(9, 7, -wAt * sFy);                                       \
+    JW(1, 8, h); JW(2, 8, wBt * sFx); JW(8, 8, 1.0); JW(9, 8, wAt * sFx);                                         \
+    JW(2, 9, h); JW(9, 9, 1.0);                                                                                   \
+    JW(2, 10, wBt * mF1y); JW(3, 10, s_m1h); JW(9, 10, wAt * mF1y); JW(10, 10, keep);                             \
+    JW(2, 11, -wBt * mF1x); JW(4, 11, s_k1h); JW(9, 11, -wAt * mF1x); JW(11, 11, keep);                           \
+    JW(2, 12, wBt * mF2y); JW(5, 12, s_m2h); JW(9, 12, wAt * mF2y); JW(12, 12, keep);                             \
+    JW(2, 13, -wBt * mF2x); JW(6, 13, s_k2h); JW(9, 13, -wAt * mF2x); JW(13, 13, keep);                           \
+    JW(14, 14, keep);                                                                                             \
+    /* columns 15-18: forces */                                                                                   \
+    JW(0, 15, h2mb); JW(2, 15, t15); JW(3, 15, s_m1h2); JW(7, 15, hmb); JW(9, 15, o15); JW(10, 15, s_k1f);        \
+    JW(1, 16, h2mb); JW(2, 16, t16); JW(4, 16, s_k1h2); JW(8, 16, hmb); JW(9, 16, o16); JW(11, 16, s_k1f);        \
+    JW(0, 17, h2mb); JW(2, 17, t17); JW(5, 17, s_m2h2); JW(7, 17, hmb); JW(9, 17, o17); JW(12, 17, s_k2f);        \
+    JW(1, 18, h2mb); JW(2, 18, t18); JW(6, 18, s_k2h2); JW(8, 18, hmb); JW(9, 18, o18); JW(13, 18, s_k2f);        \
+    /* column 19: the step length h */                                                                            \
+    JW(0, 19, hc[0]); JW(1, 19, hc[1]); JW(2, 19, hc[2]); JW(3, 19, hc[3]); JW(4, 19, hc[4]);                     \
+    JW(5, 19, hc[5]); JW(6, 19, hc[6]); JW(7, 19, hc[7]); JW(8, 19, hc[8]); JW(9, 19, hc[9]);                     \
+    JW(10, 19, hc[10]); JW(11, 19, hc[11]); JW(12, 19, hc[12]); JW(13, 19, hc[13]); JW(14, 19, hc[14])
+
 // ---------------------------------------------------------------------------------------------
 // Fused constraint + Jacobian kernel.
 // ---------------------------------------------------------------------------------------------
@@ -188,7 +224,8 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 // KC = knots per chunk = lanes that integrate a knot at a time (<= 64); the chunk's Z slice and
 //      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
 // W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
-template <int T, int KC, int W, bool WITH_C, bool WITH_J>
+// NNZ = structural format (QLN_JAC_FORMAT_STRUCTURAL): T is unused, the tile holds the chunk's KC compact blocks
+template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
                                                               double* __restrict__ V, uint32_t flags) {
@@ -198,9 +235,12 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     static_assert(KC <= kWave, "one lane per knot of a chunk");
     constexpr int kZSlice = KC * 20 + 15;
     constexpr int kCStage = (kZSlice + 1) & ~1;
-    static_assert(T * kBlk >= kCStage + KC * 15, "Z slice + residual stage must fit in the tile they alias");
-    static_assert(T * kBlk >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
-    __shared__ double2 s_j2[T * kBlk / 2];
+    // structural format: up to 71 values per knot of the chunk, +1 so that the LDS image can start at the parity of
+    // its global offset (16-byte pieces then line up on both sides)
+    constexpr int kTile = NNZ ? ((KC * 71 + 2) & ~1) : T * kBlk;
+    static_assert(kTile >= kCStage + KC * 15, "Z slice + residual stage must fit in the tile they alias");
+    static_assert(kTile >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
+    __shared__ double2 s_j2[kTile / 2];
     double* const s_j = reinterpret_cast<double*>(s_j2);
     double* const s_z = s_j;
     double* const s_c = s_j + kCStage;
@@ -248,10 +288,12 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     const int o_fc = o_co + (N - kt + 1);
     const int o_bp = o_fc + 1;
     const bool init1 = (im == 1);  // foot 1 touches first: contact-init row is y1, contact-other is y2
+    // length of the step-block section of vals
+    const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
 
     if (WITH_J && (flags & 1u)) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
-        double* Vc = Vb + kBlk * (N - 1) + N;
+        double* Vc = Vb + dyn_blocks + N;
         const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
         for (int i = lane; i < n_const; i += kWave) {
             double v;
@@ -396,15 +438,15 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const bool own = valid || (last_chunk && lane == nk);
                 const double th = s_z[20 * (own ? lane : 0) + 2];
                 const double cth = cos(th);
-                if (own) Vb[kBlk * (N - 1) + kc0 + lane] = (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
+                if (own) Vb[dyn_blocks + kc0 + lane] = (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
                 if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
                     const double tn = s_z[20 * nk + 2];
                     const double ctn = cos(tn);
-                    if (lane == 0) Vb[kBlk * (N - 1) + kc0 + nk] = (tn > 0) ? (-lb / 2 * ctn) : (lb / 2 * ctn);
+                    if (lane == 0) Vb[dyn_blocks + kc0 + nk] = (tn > 0) ? (-lb / 2 * ctn) : (lb / 2 * ctn);
                 }
             }
             wave_lds_sync();
-            {
+            if constexpr (!NNZ) {
                 // structural zeros of the tile: written here, never touched by the value writes below
                 const double2 zero2 = make_double2(0.0, 0.0);
 #pragma unroll
@@ -468,6 +510,69 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             double wAt = At, wBt = Bt, wAw = Aw;
 
             QLN_STAMP(3);
+            if constexpr (NNZ) {
+                // ---- structural format: the chunk's compact blocks are one contiguous run of vals ----
+                // Every lane writes the values of its knot's pattern (71 / 56 / 57 of them) behind those of
+                // the lane before it; lanes of different contact modes take different branches (at most
+                // three per chunk: before, at and after the transition knot).
+                const int g0 = step_block_offset(kc0, N, kt);
+                const int g1 = step_block_offset(kc0 + nk, N, kt);
+                const int p0 = g0 & 1;  // the LDS image starts at the parity of its global offset
+                if (valid) {
+                    // One pass over the pattern of the problem's contact mode (71 entries, column-major), the same
+                    // instructions for every lane.  Lanes whose knot has a sparser pattern (mode 3: 57, transition
+                    // knot: 56) pull their write pointer back by one slot after every entry their pattern lacks, so
+                    // that such an entry lands where the lane's next real entry overwrites it (a wave's DS writes
+                    // execute in order).  Only the transition knot's pattern ends early -- the masked rows 11-15 of
+                    // column 19 -- and those five writes are predicated.
+                    double* jr = s_j + p0 + (step_block_offset(k, N, kt) - g0);
+                    const int decF = (mode == 3) ? 1 : 0, decJ = jump ? 1 : 0, decFJ = decF + decJ;
+                    auto emit = [&](auto catc) {
+                        constexpr int CB = decltype(catc)::value;  // contact category of the problem: 0 or 1
+                        constexpr int CJ = CB + 3;                 // the same mode followed by the jump
+#define JW(row, col, val)                                                                   \
+    if constexpr (step_entry_present(CB, row, col)) {                                       \
+        constexpr int pos_ = step_entry_pos(CB, row, col);                                  \
+        constexpr bool inF_ = step_entry_present(2, row, col);                              \
+        constexpr bool inJ_ = step_entry_present(CJ, row, col);                             \
+        if constexpr (!inJ_ && step_entry_pos(CJ, row, col) == step_nnz(CJ)) {              \
+            if (!jump) jr[pos_] = (val); /* nothing of the jump pattern follows */          \
+        } else {                                                                            \
+            jr[pos_] = (val);                                                               \
+        }                                                                                   \
+        if constexpr (!inF_ && !inJ_) jr -= decFJ;                                          \
+        else if constexpr (!inF_) jr -= decF;                                               \
+        else if constexpr (!inJ_) jr -= decJ;                                               \
+    }
+                        QLN_STEP_ENTRIES();
+#undef JW
+                    };
+                    if (im == 1) emit(std::integral_constant<int, 0>{});
+                    else emit(std::integral_constant<int, 1>{});
+                }
+                wave_lds_sync();
+                QLN_STAMP(4);
+                {
+                    // LDS double i <-> vals[gb + i]; gb is even, so 16-byte pieces are aligned on both sides.
+                    // A leading / trailing half piece goes out as one 8-byte store.
+                    const int pe = p0 + (g1 - g0);
+                    double* gbase = Vb + (g0 - p0);
+                    if (lane == 0) {
+                        if (p0) gbase[1] = s_j[1];
+                        if (pe & 1) gbase[pe - 1] = s_j[pe - 1];
+                    }
+                    const int np = (pe >> 1) - p0;  // complete pieces, the first one is piece p0
+                    double2* dst = reinterpret_cast<double2*>(gbase) + p0 + lane;
+                    const double2* src = s_j2 + p0 + lane;
+                    int it = 0;
+#pragma unroll 1
+                    for (; (it + 6) * kWave <= np; it += 6) drain6<kWave>(lds_offset(src + it * kWave), dst + it * kWave);
+#pragma unroll 1
+                    for (; it * kWave + lane < np; ++it) dst[it * kWave] = src[it * kWave];
+                }
+                wave_lds_sync();
+                QLN_STAMP(5);
+            } else {
             // ---- assemble T knots at a time in LDS and stream them out ---------------------------
             const int nt = (nk + T - 1) / T;
 #pragma unroll 1
@@ -479,37 +584,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
 #define JW(row, col, val) jr[(row) + 15 * (col)] = (val)
                     // opaque to loop-invariant code motion (see above)
                     asm volatile("" : "+v"(wAt), "+v"(wBt), "+v"(wAw));
-#pragma unroll
-                    for (int r15 = 0; r15 < 15; ++r15) JW(r15, 19, hc[r15]);
-                    // row 2 (theta): cols 0..13, 15..18
-                    JW(2, 0, -wAt * sFy); JW(2, 1, wAt * sFx); JW(2, 2, 1.0);
-                    JW(2, 3, wAt * F1y); JW(2, 4, -wAt * F1x); JW(2, 5, wAt * F2y); JW(2, 6, -wAt * F2x);
-                    JW(2, 7, -wBt * sFy); JW(2, 8, wBt * sFx); JW(2, 9, h);
-                    JW(2, 10, wBt * mF1y); JW(2, 11, -wBt * mF1x); JW(2, 12, wBt * mF2y); JW(2, 13, -wBt * mF2x);
-                    JW(2, 15, t15); JW(2, 16, t16); JW(2, 17, t17); JW(2, 18, t18);
-                    // row 9 (omega): cols 0,1,3..13,15..18
-                    JW(9, 0, -wAw * sFy); JW(9, 1, wAw * sFx);
-                    JW(9, 3, wAw * F1y); JW(9, 4, -wAw * F1x); JW(9, 5, wAw * F2y); JW(9, 6, -wAw * F2x);
-                    JW(9, 7, -wAt * sFy); JW(9, 8, wAt * sFx); JW(9, 9, 1.0);
-                    JW(9, 10, wAt * mF1y); JW(9, 11, -wAt * mF1x); JW(9, 12, wAt * mF2y); JW(9, 13, -wAt * mF2x);
-                    JW(9, 15, o15); JW(9, 16, o16); JW(9, 17, o17); JW(9, 18, o18);
-                    // rows 0, 1 (body position)
-                    JW(0, 0, 1.0); JW(0, 7, h); JW(0, 15, h2mb); JW(0, 17, h2mb);
-                    JW(1, 1, 1.0); JW(1, 8, h); JW(1, 16, h2mb); JW(1, 18, h2mb);
-                    // rows 3..6 (foot positions; the y rows are masked at the jump)
-                    JW(3, 3, 1.0); JW(3, 10, s_m1h); JW(3, 15, s_m1h2);
-                    JW(4, 4, keep); JW(4, 11, s_k1h); JW(4, 16, s_k1h2);
-                    JW(5, 5, 1.0); JW(5, 12, s_m2h); JW(5, 17, s_m2h2);
-                    JW(6, 6, keep); JW(6, 13, s_k2h); JW(6, 18, s_k2h2);
-                    // rows 7, 8 (body velocity)
-                    JW(7, 7, 1.0); JW(7, 15, hmb); JW(7, 17, hmb);
-                    JW(8, 8, 1.0); JW(8, 16, hmb); JW(8, 18, hmb);
-                    // rows 10..13 (foot velocities), row 14 (clock): masked at the jump (quirk Q1)
-                    JW(10, 10, keep); JW(10, 15, s_k1f);
-                    JW(11, 11, keep); JW(11, 16, s_k1f);
-                    JW(12, 12, keep); JW(12, 17, s_k2f);
-                    JW(13, 13, keep); JW(13, 18, s_k2f);
-                    JW(14, 14, keep);
+                    QLN_STEP_ENTRIES();
 #undef JW
                 }
                 wave_lds_sync();
@@ -537,6 +612,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 wave_lds_sync();
                 QLN_STAMP(4 + min(t, 10));
             }
+            }  // dense blocks
         }
     }
     QLN_STAMP(15);
@@ -549,7 +625,8 @@ __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, dou
     if (b >= P.B) return;
     const int N = P.N;
     const int kt = P.desc[b].k_trans;
-    double* Vc = V + P.desc[b].j_off + kBlk * (N - 1) + N;
+    const int dyn_blocks = (P.jac_format == QLN_JAC_FORMAT_STRUCTURAL) ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
+    double* Vc = V + P.desc[b].j_off + dyn_blocks + N;
     const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
     for (int i = lane; i < n_const; i += kWave) {
         double v;
@@ -770,7 +847,7 @@ __global__ __launch_bounds__(256) void k_lqr_cost(BatchParams P, const double* _
     out[40] = a + bb;                                      // c = 0.5*xf'Q*xf + 0.5*uf'R*uf
 }
 
-template <int T, int KC, int W>
+template <int T, int KC, int W, bool NNZ = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
     dim3 grid(xcd_grid(nb)), block(kWave);
@@ -784,11 +861,11 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
     constexpr unsigned pad = 0;
 #endif
     if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, NNZ>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
     else if (c)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, NNZ>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     else
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true, NNZ>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     return hipGetLastError();
 }
 
@@ -818,8 +895,18 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         default: break;
     }
+    if (vals && p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) switch (variant) {
+        case 11: return launch_cj_t<0, 32, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 12: return launch_cj_t<0, 40, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 13: return launch_cj_t<0, 32, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 14: return launch_cj_t<0, 64, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 15: return launch_cj_t<0, 64, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        default: break;
+    }
 #endif
     if (!vals) return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+    // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
+    if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
     return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
 }
 

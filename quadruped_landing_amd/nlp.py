@@ -88,6 +88,10 @@ def _torch():
     return torch
 
 
+# layout of the step-block section of vals (include/qln_evaluator.h, QLN_JAC_FORMAT_*)
+JAC_FORMATS = {"dense_blocks": _lib.QLN_JAC_FORMAT_DENSE_BLOCKS, "structural": _lib.QLN_JAC_FORMAT_STRUCTURAL}
+
+
 class HybridNLP:
     """Batch of B landing problems with a common horizon N on one GPU.
 
@@ -97,8 +101,11 @@ class HybridNLP:
     """
 
     def __init__(self, model: PlanarQuadruped, obj, init_mode, k_trans, N: int, x0, xf, *,
-                 device: int = 0, z_stride: int = 0, align: int = 16, stream=None):
+                 device: int = 0, z_stride: int = 0, align: int = 16, stream=None, jac_format: str = "dense_blocks"):
         self.model = model
+        if jac_format not in JAC_FORMATS:
+            raise ValueError(f"jac_format must be one of {sorted(JAC_FORMATS)}")
+        self.jac_format = jac_format
         self.N = int(N)
         x0 = np.asarray(x0, dtype=np.float64)
         B = x0.shape[0] if x0.ndim == 2 else 1
@@ -130,6 +137,7 @@ class HybridNLP:
         d.x0, d.xf = self.x0.ctypes.data_as(dp), self.xf.ctypes.data_as(dp)
         d.cost = self.obj.ctypes.data_as(dp) if self.obj is not None else None
         d.cost_batch, d.z_stride, d.align = self.cost_batch, int(z_stride), int(align)
+        d.jac_format = JAC_FORMATS[jac_format]
         h = C.c_void_p()
         _lib.check(L.qln_create(C.byref(d), self.device, C.byref(h)))
         self._h = h
@@ -180,6 +188,12 @@ class HybridNLP:
         mm, nz = C.c_int32(), C.c_int32()
         _lib.check(_lib.lib().qln_problem_dims(self._h, b, C.byref(mm), C.byref(nz)))
         return mm.value, nz.value
+
+    def problem_nnz_dynamic(self, b: int = 0) -> int:
+        """State-dependent values at the head of problem b's vals segment (step blocks + N clearance entries)."""
+        nd = C.c_int32()
+        _lib.check(_lib.lib().qln_problem_nnz_dynamic(self._h, b, C.byref(nd)))
+        return nd.value
 
     def cinds(self, b: int = 0):
         out = (C.c_int32 * 14)()

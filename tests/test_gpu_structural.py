@@ -1,0 +1,178 @@
+"""GPU parity of the structural Jacobian format (QLN_JAC_FORMAT_STRUCTURAL): only the entries of every 15x20 step
+block that can be non-zero in the knot's contact mode are stored (71 / 56 / 57 per block).
+
+Checked against the CPU oracle, which produces the reference's dense blocks by forward-mode duals:
+  * the listed (row, col) positions are exactly the oracle's non-zero pattern at a generic point, per contact mode,
+    in column-major order, block after block (bit-exact indexing / sparsity);
+  * every value matches the oracle's entry at that position to 1e-8 relative (north_star tolerance);
+  * every entry the format leaves out is exactly 0.0 in the oracle's Jacobian at the SAME Z, so nothing is lost;
+  * constraints, constants, clearance entries and the MOI dense scatter are those of the dense-block format.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import oracle_batch, oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8  # north_star: "within 1e-8 relative on FP64 dynamics/Jacobian entries"
+JUMP_MASK = np.array([1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0], dtype=bool)  # src/planar_quadruped.jl:262-263
+
+
+def _oracle_patterns():
+    """Non-zero pattern of the oracle's step Jacobian per category (contact 1, contact 2, mode 3, jump 1, jump 2),
+    at generic points: the union over a few random draws, so that no entry vanishes by accident."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(123)
+    pats = []
+    for mode, jump in [(1, False), (2, False), (3, False), (1, True), (2, True)]:
+        nz = np.zeros((15, 20), dtype=bool)
+        for _ in range(4):
+            x, u = rng.normal(size=15), np.append(rng.normal(size=4), rng.uniform(0.001, 0.02))
+            J = O.contact_jacobian(mode, x, u)
+            if jump:
+                J = JUMP_MASK[:, None] * J
+            nz |= J != 0
+        pats.append(nz)
+    assert [int(p.sum()) for p in pats] == [71, 71, 57, 56, 56]
+    return pats
+
+
+def _category(K, kt, im):
+    # mode schedule of src/constraints.jl:23-37 (K = 1-based dynamics knot)
+    if K == kt - 1:
+        return 3 if im == 1 else 4
+    if K < kt - 1:
+        return 0 if im == 1 else 1
+    return 2
+
+
+def _run(batch, **kw):
+    import torch
+    from quadruped_landing_amd import HybridNLP
+
+    out = {}
+    for fmt in ("dense_blocks", "structural"):
+        nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                        jac_format=fmt, **kw)
+        Z = nlp.upload_Z(batch.Z)
+        c = torch.full((nlp.dims.c_total,), float("nan"), dtype=torch.float64, device="cuda")
+        v = torch.full((nlp.dims.j_total,), float("nan"), dtype=torch.float64, device="cuda")
+        nlp.eval_c_and_jac(Z, c, v, write_constants=True)
+        torch.cuda.synchronize()
+        out[fmt] = (nlp, c.cpu().numpy(), v.cpu().numpy())
+    return out
+
+
+def _check(batch, **kw):
+    pats = _oracle_patterns()
+    out = _run(batch, **kw)
+    nd, cd, vd = out["dense_blocks"]
+    ns, cs, vs = out["structural"]
+    ref = oracle_batch(batch, nd)  # oracle in the dense-block layout
+    N = batch.N
+    # constraints do not depend on the format
+    assert np.array_equal(cd, cs, equal_nan=True)
+    # every slot of the structural buffer that belongs to a problem is written, padding is untouched
+    written = np.zeros(vs.shape, dtype=bool)
+    worst = 0.0
+    for b in range(batch.B):
+        kt, im = int(batch.k_trans[b]), int(batch.init_mode[b])
+        m_nlp, nnz = ns.problem_dims(b)
+        _, nnz_d = nd.problem_dims(b)
+        rows, cols = ns.jacobian_structure(b)
+        rows_d, cols_d = nd.jacobian_structure(b)
+        seg = vs[ns.j_off[b] : ns.j_off[b] + nnz]
+        written[ns.j_off[b] : ns.j_off[b] + nnz] = True
+        ref_d = ref["vals"][nd.j_off[b] : nd.j_off[b] + nnz_d]
+        gpu_d = vd[nd.j_off[b] : nd.j_off[b] + nnz_d]
+        # expected structure of the step section from the oracle's patterns
+        e = 0
+        for k in range(N - 1):
+            pat = pats[_category(k + 1, kt, im)]
+            cc, rr = np.nonzero(pat.T)  # column-major order
+            n = rr.size
+            assert np.array_equal(rows[e : e + n], 29 + 15 * k + rr), (b, k)
+            assert np.array_equal(cols[e : e + n], 20 * k + cc), (b, k)
+            blk_ref = ref_d[300 * k : 300 * (k + 1)].reshape(20, 15).T  # [row, col]
+            blk_gpu = gpu_d[300 * k : 300 * (k + 1)].reshape(20, 15).T
+            # nothing is lost: what the format leaves out is exactly zero in the oracle's Jacobian at this Z
+            assert np.all(blk_ref[~pat] == 0.0), (b, k)
+            got = seg[e : e + n]
+            worst = max(worst, rel_err(got, blk_ref[rr, cc], floor=1e-300))
+            # same arithmetic as the dense-block kernel: bitwise the same values
+            assert np.array_equal(got, blk_gpu[rr, cc]), (b, k)
+            e += n
+        assert e == ns.problem_nnz_dynamic(b) - N
+        # the rest of the segment (clearance entries, constants) is the dense-block format's tail
+        assert np.array_equal(rows[e:], rows_d[300 * (N - 1) :]) and np.array_equal(cols[e:], cols_d[300 * (N - 1) :])
+        assert np.array_equal(seg[e:], gpu_d[300 * (N - 1) :])
+        assert nnz - e == nnz_d - 300 * (N - 1)
+        worst = max(worst, rel_err(seg[e:], ref_d[300 * (N - 1) :], floor=1e-300))
+    assert np.array_equal(np.isnan(vs), ~written)
+    print(f"structural format B={batch.B} N={N}: worst rel err {worst:.3e}")
+    assert worst <= RTOL
+    return out
+
+
+@pytest.mark.parametrize("B,N,kt,im", [(1, 40, 14, 1), (64, 40, 14, 1), (33, 40, 14, 2), (5, 61, 21, 1), (7, 2, 2, 1),
+                                       (3, 3, 2, 2), (4, 66, 30, 1), (2, 130, 100, 2), (3, 65, 65, 1), (2, 129, 3, 2)])
+def test_structural_uniform_batches(B, N, kt, im):
+    from quadruped_landing_amd import problem_gen as PG
+
+    _check(PG.make_batch(B, N, kt, im, seed=B + N))
+
+
+@pytest.mark.parametrize("B,N", [(257, 80), (40, 17), (16, 200)])
+def test_structural_ragged_batches(B, N):
+    from quadruped_landing_amd import problem_gen as PG
+
+    _check(PG.make_batch(B, N, seed=11, ragged=True))
+
+
+def test_structural_k_trans_extremes_and_alignment():
+    from quadruped_landing_amd import problem_gen as PG
+
+    N = 12
+    batch = PG.make_batch(6, N, seed=3, ragged=True)
+    batch.k_trans[:] = [1, 2, N - 1, N, N + 1, 5]
+    batch.init_mode[:] = [1, 2, 1, 2, 1, 2]
+    _check(batch)
+    _check(batch, align=1, z_stride=20 * N + 3)  # odd offsets: j_off stays even, pieces stay aligned
+
+
+def test_structural_counts_and_dims():
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(4, 40, 14, 1, seed=0)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                    jac_format="structural")
+    # 12 contact knots, the transition knot, 26 knots in mode 3 (SURVEY.md 8d "strict variant")
+    assert nlp.problem_nnz_dynamic(0) == 71 * 12 + 56 + 57 * 26 + 40
+    assert nlp.dims.nnz_dynamic == nlp.problem_nnz_dynamic(0)
+    m_nlp, nnz = nlp.problem_dims(0)
+    assert nnz == nlp.problem_nnz_dynamic(0) + 435 + 15 * 39 + 3 * 40 - 14 + 3
+    with pytest.raises(ValueError):
+        HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf, jac_format="csr")
+
+
+def test_structural_dense_host_scatter_is_the_reference_write_set():
+    """MOI dense mode on a structural-format handle: the whole jac_c! write-set is still assigned (quirk Q5), the
+    entries the format leaves out as explicit zeros."""
+    from oracle import oracle as O
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(3, 23, seed=4, ragged=True)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                    jac_format="structural")
+    for b in range(batch.B):
+        m_nlp, _ = nlp.problem_dims(b)
+        D = np.full((m_nlp, nlp.n_nlp), np.nan, order="F")
+        nlp.jac_c_dense_host(batch.Z[b], D, b)
+        onlp = O.OracleNLP(batch.N, int(batch.k_trans[b]), int(batch.init_mode[b]), batch.x0[b], batch.xf[b],
+                           batch.obj[b], oracle_model(batch.model))
+        Dref = onlp.jac_c_dense(batch.Z[b])
+        assert np.array_equal(np.isnan(D), np.isnan(Dref))
+        assert rel_err(D, Dref, floor=1e-300) <= RTOL
+        assert np.array_equal(D == 0, Dref == 0)

@@ -113,3 +113,25 @@ def test_trajectory_io_roundtrip(tmp_path, golden_dir):
     assert X.shape == (61, 15) and U.shape == (60, 5)
     with pytest.raises(ValueError):
         TIO.load_trajectory(str(p), 40)
+
+
+def test_bench_strict_nnz_counts_match_oracle_structure():
+    # bench.py's "strict" roofline figure counts the structurally non-zero entries of each step block:
+    # check its three constants against the oracle's forward-mode Jacobian at a generic point
+    import bench
+
+    rng = np.random.default_rng(5)
+    x, u = rng.normal(size=15), np.append(rng.normal(size=4), 0.01)
+    nnz = {m: int(np.count_nonzero(O.contact_jacobian(m, x, u))) for m in (1, 2, 3)}
+    assert nnz == {1: bench.NNZ_CONTACT, 2: bench.NNZ_CONTACT, 3: bench.NNZ_FLIGHT}
+    mask = np.array([1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0])  # src/planar_quadruped.jl:262-263 (Q1)
+    for m in (1, 2):
+        assert int(np.count_nonzero(mask[:, None] * O.contact_jacobian(m, x, u))) == bench.NNZ_JUMP
+    # whole problem, against the block-COO values of a full evaluation
+    N, kt = 12, 5
+    prob = O.OracleNLP(N, kt, 1, rng.normal(size=15), rng.normal(size=15), np.zeros((N, 41)))
+    Z = rng.normal(size=prob.n_nlp)
+    Z[19::20] = 0.01
+    vals = prob.jac_c_coo(Z)
+    dyn_nnz = int(np.count_nonzero(vals[: 300 * (N - 1)]))
+    assert int(bench.strict_bytes(N, kt)) == 8 * (20 * N - 5) + 8 * prob.m_nlp + 8 * (dyn_nnz + N)
