@@ -1,20 +1,21 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun):  bench/profile_round.sh r01 [workload]
+# usage (on the GPU box, via gpurun):  bench/profile_round.sh r01 [workload] [dense_blocks|structural]
 # 1. rocprofv3 --kernel-trace --stats of the default bench command  -> kernel_stats.csv
 # 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ set)          -> pmc_summary.txt, traffic.json
 # Everything lands in gpurun_out/profile_<tag>/ ; copy what should be judged into profiles/.
-TAG=${1:-r01}; WL=${2:-config3}
+TAG=${1:-r01}; WL=${2:-config3}; FMT=${3:-dense_blocks}
+KEY=$WL; [ "$FMT" = structural ] && KEY=${WL}_structural
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --jac-format $FMT --steps 20 --warmup 3 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_p$i -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/pmc_p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_p$i.log; exit 1; }
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_p$i -- python3 $R/bench.py --workload $WL --jac-format $FMT --steps 5 --warmup 1 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/pmc_p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_p$i.log; exit 1; }
 done
 python3 $R/bench/pmc_summary.py k_constraint_jacobian $OUT/pmc_p* > $OUT/pmc_summary.txt
 python3 - <<PY
@@ -27,7 +28,7 @@ for line in open("$OUT/pmc_summary.txt"):
 # (MI355X_MICROARCH.md HBM section; re-calibrated here with bench/store_ceiling.hip: profiles/calibration_*.txt);
 # WRITE_SIZE (KiB) is exact.
 fetch=2*vals["FETCH_SIZE"]*1024; write=vals["WRITE_SIZE"]*1024
-json.dump({"$WL":{"hbm_bytes_per_launch":fetch+write,"fetch_bytes_corrected":fetch,"write_bytes":write,
+json.dump({"$KEY":{"hbm_bytes_per_launch":fetch+write,"fetch_bytes_corrected":fetch,"write_bytes":write,
   "FETCH_SIZE_KiB_raw":vals["FETCH_SIZE"],"WRITE_SIZE_KiB_raw":vals["WRITE_SIZE"],
   "note":"per launch of k_constraint_jacobian; fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024"}},
   open("$OUT/traffic.json","w"),indent=1)

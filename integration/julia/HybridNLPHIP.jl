@@ -14,6 +14,7 @@ struct QlnBatchDesc
     B::Int32; N::Int32; model::QlnModel
     k_trans::Ptr{Int32}; init_mode::Ptr{Int32}; x0::Ptr{Cdouble}; xf::Ptr{Cdouble}; cost::Ptr{Cdouble}
     cost_batch::Int32; z_stride::Int64; align::Int32
+    jac_format::Int32      # 0 = dense 15x20 step blocks, 1 = structural non-zeros only (QLN_JAC_FORMAT_*)
 end
 
 qln_check(rc) = rc == 0 || error("libqln_hip: " * unsafe_string(ccall((:qln_last_error, LIBQLN), Cstring, ())))
@@ -29,12 +30,14 @@ end
 # HybridNLP(model, obj, init_mode, k_trans, N, x0, xf) -- src/nlp.jl:34-37.  `obj` is the reference's
 # Vector{QuadraticCost}; it is flattened to the 41-double records [Q(15) R(5) q(15) r(5) c].
 function HybridNLPHIP(model, obj, init_mode, k_trans, N, x0, xf; use_sparse_jacobian=false, device=0)
+    # a sparse solve wants only the entries that can be non-zero; the dense callback needs neither format in particular
+    jac_format = use_sparse_jacobian ? 1 : 0
     cost = vcat([[diag(o.Q); diag(o.R); o.q; o.r; o.c] for o in obj]...)
     kt = Int32[k_trans]; im = Int32[init_mode]; x0v = collect(Float64, x0); xfv = collect(Float64, xf)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve cost kt im x0v xfv begin
         d = Ref(QlnBatchDesc(1, N, QlnModel(model.g, model.mb, model.mf, model.lb, model.l1, model.l2),
-                             pointer(kt), pointer(im), pointer(x0v), pointer(xfv), pointer(cost), 1, 0, 0))
+                             pointer(kt), pointer(im), pointer(x0v), pointer(xfv), pointer(cost), 1, 0, 0, jac_format))
         qln_check(ccall((:qln_create, LIBQLN), Cint, (Ref{QlnBatchDesc}, Cint, Ref{Ptr{Cvoid}}), d, device, h))
     end
     m = Ref{Int32}(0); nnz = Ref{Int32}(0)

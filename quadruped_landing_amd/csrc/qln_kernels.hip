@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
         }
 
         QLN_STAMP(1);
+        double cos_th = 0.0, cos_tn = 0.0;  // cos(theta) of the lane's knot / of x_N, value phase -> Jacobian phase
         // ============================== value phase (eval_c!) ==================================
         if (WITH_C) {
             double x[15], u[5], xnext[15];
@@ -393,11 +394,17 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             {
                 const bool own = valid || (last_chunk && lane == nk);
                 const double* zk = s_z + 20 * (own ? lane : 0);
-                const double cl = zk[1] - lb / 2 * fabs(sin(zk[2]));
+                double sth;
+                if constexpr (WITH_J) sincos(zk[2], &sth, &cos_th);  // the Jacobian phase needs cos(theta_k) (one call)
+                else sth = sin(zk[2]);
+                const double cl = zk[1] - lb / 2 * fabs(sth);
                 if (own) Cb[o_bp + kc0 + lane] = cl;
                 if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
                     const double* zn = s_z + 20 * nk;
-                    const double cn = zn[1] - lb / 2 * fabs(sin(zn[2]));
+                    double stn;
+                    if constexpr (WITH_J) sincos(zn[2], &stn, &cos_tn);
+                    else stn = sin(zn[2]);
+                    const double cn = zn[1] - lb / 2 * fabs(stn);
                     if (lane == 0) Cb[o_bp + kc0 + nk] = cn;
                 }
             }
@@ -437,11 +444,11 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             {
                 const bool own = valid || (last_chunk && lane == nk);
                 const double th = s_z[20 * (own ? lane : 0) + 2];
-                const double cth = cos(th);
+                const double cth = WITH_C ? cos_th : cos(th);
                 if (own) Vb[dyn_blocks + kc0 + lane] = (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
                 if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
                     const double tn = s_z[20 * nk + 2];
-                    const double ctn = cos(tn);
+                    const double ctn = WITH_C ? cos_tn : cos(tn);
                     if (lane == 0) Vb[dyn_blocks + kc0 + nk] = (tn > 0) ? (-lb / 2 * ctn) : (lb / 2 * ctn);
                 }
             }
