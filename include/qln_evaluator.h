@@ -143,6 +143,14 @@ int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, u
 /* The fused hot path: eval_c! and jac_c! of every knot of every problem in one launch. */
 int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags);
 int qln_jacobian_init_constants(qln_handle* h, double* vals);
+/* Products with the constraint Jacobian of jac_c! (src/constraints.jl:212-291) at Z, for the caller side of the path
+ * (solver iterations on the GPU).  The Jacobian is not read from memory: every step block is re-derived
+ * from Z in registers, so no vals buffer is involved and the result is the same for either jac_format.
+ *   qln_eval_constraint_jvp:  y = J(Z) v      v: layout of Z (z_stride), y: layout of c (c_off)
+ *   qln_eval_constraint_vjp:  g = J(Z)^T lam  lam: layout of c, g: layout of Z (entries past n_nlp are not touched)
+ * Device pointers, stream-ordered. */
+int qln_eval_constraint_jvp(qln_handle* h, const double* Z, const double* v, double* y);
+int qln_eval_constraint_vjp(qln_handle* h, const double* Z, const double* lam, double* g);
 /* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
  * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
  * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */

@@ -91,6 +91,8 @@ SIGNATURES = {
     "qln_eval_constraint_jacobian": (C.c_int, [_vp, _dp, _dp, C.c_uint32]),
     "qln_eval_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32]),
     "qln_jacobian_init_constants": (C.c_int, [_vp, _dp]),
+    "qln_eval_constraint_jvp": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "qln_eval_constraint_vjp": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
     "qln_set_lqr_cost": (C.c_int, [_vp, _dp, _dp, _dp, C.c_double, C.c_int]),

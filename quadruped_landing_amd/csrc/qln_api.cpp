@@ -438,6 +438,22 @@ int qln_constraint_violation(qln_handle* h, const double* c, double* viol) {
     return QLN_OK;
 }
 
+int qln_eval_constraint_jvp(qln_handle* h, const double* Z, const double* v, double* y) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !v || !y) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jvp: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_jvp(h->p, Z, v, y, h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_constraint_vjp(qln_handle* h, const double* Z, const double* lam, double* g) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !lam || !g) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_vjp: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_constraint_vjp(h->p, Z, lam, g, h->stream));
+    return QLN_OK;
+}
+
 int qln_initial_guess(qln_handle* h, double* Z) {
     if (int rc = check_handle(h)) return rc;
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");

@@ -112,6 +112,9 @@ hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hi
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream);
 hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t stream);
 hipError_t launch_constraint_violation(const BatchParams& p, const double* c, double* viol, hipStream_t stream);
+// y = J(Z) v and g = J(Z)^T lam with the constraint Jacobian re-derived in registers (qln_solver_kernels.hip)
+hipError_t launch_constraint_jvp(const BatchParams& p, const double* Z, const double* v, double* y, hipStream_t stream);
+hipError_t launch_constraint_vjp(const BatchParams& p, const double* Z, const double* lam, double* g, hipStream_t stream);
 hipError_t launch_lqr_cost(const BatchParams& p, const double* qrqf, double dt, double* cost, int cost_batch,
                            hipStream_t stream);
 

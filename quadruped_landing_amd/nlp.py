@@ -316,6 +316,24 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
         return vals
 
+    def jac_vec(self, Z, v, out=None):
+        """y = jac_c(Z) @ v for every problem (v in Z's layout, y in c's); the Jacobian is re-derived in registers."""
+        self._check(Z, self.dims.z_total, "Z")
+        self._check(v, self.dims.z_total, "v")
+        out = self.new_c() if out is None else out
+        self._check(out, self.dims.c_total, "out")
+        _lib.check(_lib.lib().qln_eval_constraint_jvp(self._h, Z.data_ptr(), v.data_ptr(), out.data_ptr()))
+        return out
+
+    def jac_t_vec(self, Z, lam, out=None):
+        """g = jac_c(Z)' @ lam for every problem (lam in c's layout, g in Z's)."""
+        self._check(Z, self.dims.z_total, "Z")
+        self._check(lam, self.dims.c_total, "lam")
+        out = self.new_Z() if out is None else out
+        self._check(out, self.dims.z_total, "out")
+        _lib.check(_lib.lib().qln_eval_constraint_vjp(self._h, Z.data_ptr(), lam.data_ptr(), out.data_ptr()))
+        return out
+
     def constraint_violation(self, c, out=None):
         """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
         out = self.new_f() if out is None else out
