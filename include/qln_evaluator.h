@@ -151,6 +151,23 @@ int qln_jacobian_init_constants(qln_handle* h, double* vals);
  * Device pointers, stream-ordered. */
 int qln_eval_constraint_jvp(qln_handle* h, const double* Z, const double* v, double* y);
 int qln_eval_constraint_vjp(qln_handle* h, const double* Z, const double* lam, double* g);
+/* One Gauss-Newton step on the constraint violation for every problem of the batch (the solver
+ * iteration on the GPU, consuming the Jacobian where it is produced).  For problem b
+ *     dZ_b = D x,  x = the minimum-norm minimiser of || A D x + rho ||_2   (subject to ||x|| <= radius[b] if given),
+ * rho_i = c_i on the equality rows, min(c_i, 0) on the clearance rows (bounds of src/nlp.jl:66-69), A = jac_c(Z) without
+ * the rows of satisfied clearance constraints, D = diag(col_scale) (NULL = identity; a zero holds a variable fixed).
+ * Computed by at most max_iters CGLS iterations, stopped early once ||(AD)'(A dZ + rho)|| <= rel_tol * ||(AD)' rho|| or
+ * when the iterate leaves the trust radius (it is then cut at the boundary, Steihaug-Toint).  One wavefront per
+ * problem with every vector in LDS; the Jacobian is re-derived from Z inside the products and never stored.
+ * c = eval_c!(Z) as written by qln_eval_constraint.  radius: [B] or NULL; col_scale: [n_nlp] or NULL (shared by all
+ * problems).  info (may be NULL): QLN_GN_INFO_STRIDE doubles per problem {iterations done, ||(AD)' rho||^2,
+ * ||(AD)'(A dZ + rho)||^2, ||A dZ + rho||^2 (the linear model's prediction), ||rho||^2, 1 if cut at the radius,
+ * ||x||, 0}.  dZ has the layout of Z.  QLN_ERR_UNSUPPORTED if a problem does not fit the 160 KB of LDS of a CU
+ * (N > 149).  Device pointers, stream-ordered. */
+#define QLN_GN_INFO_STRIDE 8
+int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, double* dZ, int32_t max_iters, double rel_tol,
+                          const double* radius /*[B] or NULL*/, const double* col_scale /*[n_nlp] or NULL*/,
+                          double* info /*[B][QLN_GN_INFO_STRIDE] or NULL*/);
 /* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
  * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
  * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */

@@ -22,6 +22,7 @@ QLN_JAC_FORMAT_DENSE_BLOCKS = 0
 QLN_JAC_FORMAT_STRUCTURAL = 1
 
 NX, NU, NZ, COST_STRIDE = 15, 5, 20, 41
+GN_INFO_STRIDE = 8
 
 
 class QlnModel(C.Structure):
@@ -93,6 +94,7 @@ SIGNATURES = {
     "qln_jacobian_init_constants": (C.c_int, [_vp, _dp]),
     "qln_eval_constraint_jvp": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_eval_constraint_vjp": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "qln_gauss_newton_step": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
     "qln_set_lqr_cost": (C.c_int, [_vp, _dp, _dp, _dp, C.c_double, C.c_int]),

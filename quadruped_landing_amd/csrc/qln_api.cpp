@@ -454,6 +454,19 @@ int qln_eval_constraint_vjp(qln_handle* h, const double* Z, const double* lam, d
     return QLN_OK;
 }
 
+int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, double* dZ, int32_t max_iters, double rel_tol,
+                          const double* radius, const double* col_scale, double* info) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c || !dZ) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_gauss_newton_step: null pointer");
+    if (max_iters < 0 || !(rel_tol >= 0.0)) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_gauss_newton_step: bad max_iters / rel_tol");
+    if (qln::gauss_newton_lds_bytes(h->dims.N) > 160 * 1024)
+        return fail(QLN_ERR_UNSUPPORTED, "qln_gauss_newton_step: N = " + std::to_string(h->dims.N) +
+                                             " does not fit one problem in the 160 KB of LDS of a CU (N <= 149)");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_gauss_newton_step(h->p, Z, c, dZ, max_iters, rel_tol, radius, col_scale, info, h->stream));
+    return QLN_OK;
+}
+
 int qln_initial_guess(qln_handle* h, double* Z) {
     if (int rc = check_handle(h)) return rc;
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");

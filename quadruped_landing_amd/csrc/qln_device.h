@@ -115,6 +115,11 @@ hipError_t launch_constraint_violation(const BatchParams& p, const double* c, do
 // y = J(Z) v and g = J(Z)^T lam with the constraint Jacobian re-derived in registers (qln_solver_kernels.hip)
 hipError_t launch_constraint_jvp(const BatchParams& p, const double* Z, const double* v, double* y, hipStream_t stream);
 hipError_t launch_constraint_vjp(const BatchParams& p, const double* Z, const double* lam, double* g, hipStream_t stream);
+// batched Gauss-Newton step on the constraint violation, CGLS per problem in LDS (qln_solver_kernels.hip)
+size_t gauss_newton_lds_bytes(int32_t N);
+hipError_t launch_gauss_newton_step(const BatchParams& p, const double* Z, const double* c, double* dZ, int max_iters,
+                                    double rel_tol, const double* radius, const double* col_scale, double* info,
+                                    hipStream_t stream);
 hipError_t launch_lqr_cost(const BatchParams& p, const double* qrqf, double dt, double* cost, int cost_batch,
                            hipStream_t stream);
 

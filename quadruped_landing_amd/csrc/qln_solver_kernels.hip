@@ -209,6 +209,257 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Batched Gauss-Newton step on the constraint violation: for every problem
+//     dZ = argmin || A dZ + rho ||_2   of minimum norm,
+// where rho_i = c_i on the equality rows and min(c_i, 0) on the clearance rows (the bounds of src/nlp.jl:66-69),
+// and A = jac_c(Z) with the rows of satisfied clearance constraints removed.  Solved by CGLS (conjugate gradients on
+// the normal equations, started at 0, so the iterates stay in range(A') and converge to the minimum-norm solution
+// even though A is rank deficient).  One wavefront owns one problem and keeps EVERYTHING in LDS -- Z, the five CGLS
+// vectors and the clearance mask -- so an iteration touches no global memory at all; A is never formed: both products
+// re-derive each step block from Z in registers.  HBM traffic of a whole step: read Z and c, write dZ.
+// Optional: a diagonal column scaling D (variables of very different magnitude: forces ~1e2, time steps ~1e-2; a zero
+// holds a variable fixed, e.g. one sitting on a bound) and a per-problem trust radius on ||D^-1 dZ|| (Steihaug-Toint
+// truncation), which is what an outer trust-region loop needs.
+// LDS per problem: (5 n_nlp + 2 m_nlp + N) doubles = 43 KB at N = 40, 87 KB at N = 80; N <= 149 fits the 160 KB of a CU.
+// ---------------------------------------------------------------------------------------------
+struct ModelConst {
+    double g, mb, mf, lb, Ib;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// y = A v, all operands in LDS (z, v: layout of Z; y: layout of c; mask[k] = 1 if clearance row k is active)
+// (A D) v: the columns of A are scaled by dsc (0 = variable held fixed)
+__device__ __forceinline__ void lds_jvp(const ProblemView& pv, const ModelConst& M, const double* z, const double* v,
+                                        const double* dsc, const double* mask, double* y, int lane) {
+    const int N = pv.N, kt = pv.kt, im = pv.im;
+    const double g = M.g, mb = M.mb, mf = M.mf, lb = M.lb, Ib = M.Ib;
+    if (lane < 15) y[lane] = dsc[lane] * v[lane];
+    if (lane >= 15 && lane < 29) y[lane] = dsc[20 * (N - 1) + (lane - 15)] * v[20 * (N - 1) + (lane - 15)];
+    if (lane == 29)
+        y[pv.o_fc] = dsc[20 * (N - 2) + 16] * v[20 * (N - 2) + 16] + dsc[20 * (N - 2) + 18] * v[20 * (N - 2) + 18];
+    for (int k0 = 0; k0 < N; k0 += kWave) {
+        const int kk = k0 + lane, K = kk + 1;
+        const bool own = kk < N, valid = kk < N - 1;
+        const double* zk = z + 20 * (own ? kk : 0);
+        const double* vk = v + 20 * (own ? kk : 0);
+        const double* dk = dsc + 20 * (own ? kk : 0);
+        const double dth = clearance_dtheta(zk[2], lb);
+        if (own) {
+            const double v4 = dk[4] * vk[4], v6 = dk[6] * vk[6];
+            y[pv.o_ci + kk] = pv.init1 ? v4 : v6;
+            if (K >= kt) y[pv.o_co + (K - kt)] = pv.init1 ? v6 : v4;
+            y[pv.o_bp + kk] = mask[kk] * (dk[1] * vk[1] + dth * (dk[2] * vk[2]));
+        }
+        if (valid) {
+            double x[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) x[i] = zk[i];
+            const double F1x = zk[15], F1y = zk[16], F2x = zk[17], F2y = zk[18], h = zk[19];
+            const int mode = (K <= kt - 1) ? im : 3;
+            const bool jump = (K == kt - 1), f1free = (mode == 2), f2free = (mode == 1);
+            QLN_STEP_BASE();
+            double vin[20], acc[15];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) vin[i] = dk[i] * vk[i];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) acc[i] = 0.0;
+#define JW(row, col, val) acc[row] += (val) * vin[col]
+            QLN_STEP_ENTRIES();
+#undef JW
+#pragma unroll
+            for (int i = 0; i < 15; ++i) y[pv.o_dyn + 15 * kk + i] = acc[i] - dk[20 + i] * vk[20 + i];
+        }
+    }
+}
+
+// gz = A' lam, all operands in LDS
+// (A D)' lam
+__device__ __forceinline__ void lds_vjp(const ProblemView& pv, const ModelConst& M, const double* z, const double* lam,
+                                        const double* dsc, const double* mask, double* gz, int lane) {
+    const int N = pv.N, kt = pv.kt, im = pv.im;
+    const double g = M.g, mb = M.mb, mf = M.mf, lb = M.lb, Ib = M.Ib;
+    for (int k0 = 0; k0 < N; k0 += kWave) {
+        const int kk = k0 + lane, K = kk + 1;
+        const bool own = kk < N, valid = kk < N - 1;
+        const double* zk = z + 20 * (own ? kk : 0);
+        double gk[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) gk[i] = 0.0;
+        if (valid) {
+            double x[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) x[i] = zk[i];
+            const double F1x = zk[15], F1y = zk[16], F2x = zk[17], F2y = zk[18], h = zk[19];
+            const int mode = (K <= kt - 1) ? im : 3;
+            const bool jump = (K == kt - 1), f1free = (mode == 2), f2free = (mode == 1);
+            QLN_STEP_BASE();
+            double l[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) l[i] = lam[pv.o_dyn + 15 * kk + i];
+#define JW(row, col, val) gk[col] += (val) * l[row]
+            QLN_STEP_ENTRIES();
+#undef JW
+        }
+        const double dth = clearance_dtheta(zk[2], lb);
+        if (own) {
+            if (kk >= 1) {
+#pragma unroll
+                for (int i = 0; i < 15; ++i) gk[i] -= lam[pv.o_dyn + 15 * (kk - 1) + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 15; ++i) gk[i] += lam[i];
+            }
+            if (kk == N - 1) {
+#pragma unroll
+                for (int i = 0; i < 14; ++i) gk[i] += lam[15 + i];
+            }
+            const double l_ci = lam[pv.o_ci + kk];
+            const double l_co = (K >= kt) ? lam[pv.o_co + (K - kt)] : 0.0;
+            gk[4] += pv.init1 ? l_ci : l_co;
+            gk[6] += pv.init1 ? l_co : l_ci;
+            if (kk == N - 2) {
+                const double l_fc = lam[pv.o_fc];
+                gk[16] += l_fc;
+                gk[18] += l_fc;
+            }
+            const double l_bp = mask[kk] * lam[pv.o_bp + kk];
+            gk[1] += l_bp;
+            gk[2] += dth * l_bp;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) gz[20 * kk + i] = dsc[20 * kk + i] * gk[i];
+            if (valid) {
+#pragma unroll
+                for (int i = 15; i < 20; ++i) gz[20 * kk + i] = dsc[20 * kk + i] * gk[i];
+            }
+        }
+    }
+}
+
+// info[b][8] = {iterations, ||(AD)' rho||^2, ||(AD)'(A dZ + rho)||^2 at exit, ||A dZ + rho||^2 at exit, ||rho||^2,
+//              1 if the step was cut at the trust radius, ||D^-1 dZ||, 0}
+__global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, const double* __restrict__ Z,
+                                                                const double* __restrict__ C, double* __restrict__ DZ,
+                                                                int max_iters, double rel_tol,
+                                                                const double* __restrict__ radius,
+                                                                const double* __restrict__ col_scale,
+                                                                double* __restrict__ info) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;  // wave-uniform
+    const ProblemDesc pd = P.desc[b];
+    const ProblemView pv = view_of(P, pd);
+    const int N = pv.N, n = 20 * N - 5, m = 18 * N - pv.kt + 16;
+    ModelConst M;
+    M.g = P.g, M.mb = P.mb, M.mf = P.mf, M.lb = P.lb;
+    M.Ib = P.mb * (P.lb * P.lb) / 12;
+    double* z = lds;        // [n]  decision vector
+    double* x = z + n;      // [n]  CGLS solution, in scaled variables: dZ = D x
+    double* p = x + n;      // [n]  search direction
+    double* s = p + n;      // [n]  (A D)' r
+    double* dsc = s + n;    // [n]  column scaling D
+    double* r = dsc + n;    // [m]  residual -(A D x + rho)
+    double* q = r + m;      // [m]  A D p
+    double* mask = q + m;   // [N]  1 = clearance row active (violated)
+    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+    const double* __restrict__ Cb = C + pd.c_off;
+    for (int i = lane; i < n; i += kWave) {
+        z[i] = Zb[i];
+        x[i] = 0.0;
+        dsc[i] = col_scale ? col_scale[i] : 1.0;
+    }
+    double phi0 = 0.0;
+    for (int i = lane; i < m; i += kWave) {
+        const double ci = Cb[i];
+        const bool ineq = i >= pv.o_bp;
+        const double rho = (ineq && !(ci < 0)) ? 0.0 : ci;  // a NaN in c propagates
+        r[i] = -rho;
+        phi0 += rho * rho;
+        if (ineq) mask[i - pv.o_bp] = (ci < 0 || ci != ci) ? 1.0 : 0.0;
+    }
+    phi0 = wave_sum(phi0);
+    wave_lds_sync();
+    lds_vjp(pv, M, z, r, dsc, mask, s, lane);
+    wave_lds_sync();
+    double gamma = 0.0;
+    for (int i = lane; i < n; i += kWave) {
+        const double si = s[i];
+        p[i] = si;
+        gamma += si * si;
+    }
+    gamma = wave_sum(gamma);
+    const double gamma0 = gamma;
+    const double delta2 = radius ? radius[b] * radius[b] : -1.0;  // trust radius on ||x|| = ||D^-1 dZ||; none if null
+    double xx = 0.0;  // ||x||^2
+    double hit = 0.0;
+    int it = 0;
+    while (it < max_iters && gamma > rel_tol * rel_tol * gamma0) {  // wave-uniform; false for NaN
+        wave_lds_sync();
+        lds_jvp(pv, M, z, p, dsc, mask, q, lane);
+        wave_lds_sync();
+        double qq = 0.0;
+        for (int i = lane; i < m; i += kWave) qq += q[i] * q[i];
+        qq = wave_sum(qq);
+        if (!(qq > 0.0)) break;
+        double alpha = gamma / qq;
+        if (radius) {
+            // Steihaug-Toint: CGLS iterates grow in norm, so the first one to leave the ball is cut at its boundary
+            double xp = 0.0, pp = 0.0;
+            for (int i = lane; i < n; i += kWave) {
+                xp += x[i] * p[i];
+                pp += p[i] * p[i];
+            }
+            xp = wave_sum(xp);
+            pp = wave_sum(pp);
+            const double xn2 = xx + 2.0 * alpha * xp + alpha * alpha * pp;
+            if (xn2 >= delta2) {
+                alpha = (-xp + sqrt(xp * xp + pp * (delta2 - xx))) / pp;
+                hit = 1.0;
+            }
+            xx = xx + 2.0 * alpha * xp + alpha * alpha * pp;
+        }
+        for (int i = lane; i < n; i += kWave) x[i] += alpha * p[i];
+        for (int i = lane; i < m; i += kWave) r[i] -= alpha * q[i];
+        wave_lds_sync();
+        lds_vjp(pv, M, z, r, dsc, mask, s, lane);
+        wave_lds_sync();
+        double gnew = 0.0;
+        for (int i = lane; i < n; i += kWave) gnew += s[i] * s[i];
+        gnew = wave_sum(gnew);
+        const double beta = gnew / gamma;
+        for (int i = lane; i < n; i += kWave) p[i] = s[i] + beta * p[i];
+        gamma = gnew;
+        ++it;
+        if (hit != 0.0) break;
+    }
+    wave_lds_sync();
+    double rr = 0.0, xn = 0.0;
+    for (int i = lane; i < m; i += kWave) rr += r[i] * r[i];
+    for (int i = lane; i < n; i += kWave) xn += x[i] * x[i];
+    rr = wave_sum(rr);
+    xn = wave_sum(xn);
+    double* __restrict__ Db = DZ + (int64_t)b * P.z_stride;
+    for (int i = lane; i < n; i += kWave) Db[i] = dsc[i] * x[i];
+    if (info && lane == 0) {
+        double* o = info + 8 * (int64_t)b;
+        o[0] = (double)it;
+        o[1] = gamma0;
+        o[2] = gamma;
+        o[3] = rr;
+        o[4] = phi0;
+        o[5] = hit;
+        o[6] = sqrt(xn);
+        o[7] = 0.0;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_constraint_jvp(const BatchParams& p, const double* Z, const double* v, double* y, hipStream_t stream) {
@@ -218,6 +469,21 @@ hipError_t launch_constraint_jvp(const BatchParams& p, const double* Z, const do
 
 hipError_t launch_constraint_vjp(const BatchParams& p, const double* Z, const double* lam, double* g, hipStream_t stream) {
     hipLaunchKernelGGL(k_constraint_vjp, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, lam, g);
+    return hipGetLastError();
+}
+
+// LDS bytes one problem of the Gauss-Newton step needs (largest m_nlp is at k_trans = 1)
+size_t gauss_newton_lds_bytes(int32_t N) { return sizeof(double) * (size_t)(5 * (20 * N - 5) + 2 * (18 * N + 15) + N); }
+
+hipError_t launch_gauss_newton_step(const BatchParams& p, const double* Z, const double* c, double* dZ, int max_iters,
+                                    double rel_tol, const double* radius, const double* col_scale, double* info,
+                                    hipStream_t stream) {
+    const size_t lds = gauss_newton_lds_bytes(p.N);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss_newton_step),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gauss_newton_step, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, Z, c, dZ, max_iters, rel_tol,
+                       radius, col_scale, info);
     return hipGetLastError();
 }
 

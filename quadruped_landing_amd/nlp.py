@@ -334,6 +334,23 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_eval_constraint_vjp(self._h, Z.data_ptr(), lam.data_ptr(), out.data_ptr()))
         return out
 
+    def gauss_newton_step(self, Z, c, out=None, max_iters: int = 200, rel_tol: float = 1e-10, radius=None,
+                          col_scale=None, info=None):
+        """dZ = D x, x the minimum-norm least-squares step on the constraint violation of every problem (CGLS in LDS,
+        one wave per problem); `c` = eval_c(Z).  Optional device tensors: `radius` (B,) trust radius on |x|,
+        `col_scale` (n_nlp,) diagonal of D (0 = variable held fixed), `info` (B, 8): {iterations, |(AD)'rho|^2,
+        |(AD)'(A dZ + rho)|^2, |A dZ + rho|^2, |rho|^2, cut at the radius, |x|, 0}."""
+        self._check(Z, self.dims.z_total, "Z")
+        self._check(c, self.dims.c_total, "c")
+        out = self.new_Z() if out is None else out
+        self._check(out, self.dims.z_total, "out")
+        ptr = lambda t, total, name: None if t is None else self._check(t, total, name)
+        _lib.check(_lib.lib().qln_gauss_newton_step(self._h, Z.data_ptr(), c.data_ptr(), out.data_ptr(), int(max_iters),
+                                                    float(rel_tol), ptr(radius, self.B, "radius"),
+                                                    ptr(col_scale, self.n_nlp, "col_scale"),
+                                                    ptr(info, _lib.GN_INFO_STRIDE * self.B, "info")))
+        return out
+
     def constraint_violation(self, c, out=None):
         """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
         out = self.new_f() if out is None else out
