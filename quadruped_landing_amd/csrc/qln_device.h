@@ -87,6 +87,22 @@ __host__ __device__ constexpr int step_entry_pos(int cat, int row, int col) {
 }
 
 __host__ __device__ constexpr int step_nnz(int cat) { return step_entry_pos(cat, 15, 19); }
+
+// union of the five patterns (85 entries) and the position of an entry inside it (column-major)
+constexpr int kStepUnion = 85;
+__host__ __device__ constexpr bool step_union_present(int row, int col) {
+    return step_entry_present(0, row, col) || step_entry_present(1, row, col);
+}
+__host__ __device__ constexpr int step_union_pos(int row, int col) {
+    int n = 0;
+    for (int c = 0; c <= col; ++c)
+        for (int r = 0; r < 15; ++r) {
+            if (c == col && r == row) return n;
+            if (step_union_present(r, c)) ++n;
+        }
+    return n;
+}
+static_assert(step_union_pos(15, 19) == kStepUnion, "the union of the patterns has 85 entries");
 static_assert(step_nnz(0) == 71 && step_nnz(1) == 71 && step_nnz(2) == 57 && step_nnz(3) == 56 && step_nnz(4) == 56,
               "structural non-zero counts of SURVEY.md 8.0");
 

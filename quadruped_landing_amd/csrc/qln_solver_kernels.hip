@@ -13,6 +13,9 @@
 // dynamics knots so that lane nk is free for the knot behind the chunk (the terminal knot x_N in the last one).
 #include "qln_kernel_common.h"
 
+// Nothing here has to round like the reference (the products are compared with the oracle to 1e-8), so a*b+c may fuse.
+#pragma clang fp contract(fast)
+
 namespace qln {
 namespace {
 
@@ -45,9 +48,19 @@ __device__ __forceinline__ double clearance_dtheta(double th, double lb) {
     return (th > 0) ? (-lb / 2 * cth) : (lb / 2 * cth);
 }
 
-// coalesced copy of n doubles global -> LDS by one wave
-__device__ __forceinline__ void stage(double* dst, const double* __restrict__ src, int n, int lane) {
-    for (int i = lane; i < n; i += kWave) dst[i] = src[i];
+// Coalesced copy of n <= kPZ doubles global -> LDS by one wave, every load in flight before the first wait (a plain
+// copy loop is one memory round trip per 64 doubles).  Indices past n are clamped, not predicated; dst has room for
+// kStageIters * 64 doubles.
+constexpr int kStageIters = (kPZ + kWave - 1) / kWave;
+constexpr int kStageRoom = kStageIters * kWave;
+
+__device__ __forceinline__ void stage_load(double (&reg)[kStageIters], const double* __restrict__ src, int n, int lane) {
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) reg[it] = src[min(it * kWave + lane, n - 1)];
+}
+__device__ __forceinline__ void stage_store(double* dst, const double (&reg)[kStageIters], int lane) {
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) dst[it * kWave + lane] = reg[it];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -55,7 +68,7 @@ __device__ __forceinline__ void stage(double* dst, const double* __restrict__ sr
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_constraint_jvp(BatchParams P, const double* __restrict__ Z,
                                                          const double* __restrict__ V, double* __restrict__ Y) {
-    __shared__ double s_z[kPZ + 1], s_v[kPZ + 1], s_y[kPC * 15 + 1];
+    __shared__ double s_z[kStageRoom], s_v[kStageRoom], s_y[kPC * 15 + 1];
     const int lane = threadIdx.x;
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     if (b >= P.B) return;  // wave-uniform
@@ -72,10 +85,15 @@ __global__ __launch_bounds__(kWave) void k_constraint_jvp(BatchParams P, const d
         const int nk = min(kPC, N - 1 - kc0);
         const int nz = 20 * nk + 15;
         const bool first_chunk = (kc0 == 0), last_chunk = (kc0 + nk == N - 1);
-        wave_lds_sync();
-        stage(s_z, Zb + 20 * kc0, nz, lane);
-        stage(s_v, Vb + 20 * kc0, nz, lane);
-        wave_lds_sync();
+        {
+            double zr[kStageIters], vr[kStageIters];
+            stage_load(zr, Zb + 20 * kc0, nz, lane);
+            stage_load(vr, Vb + 20 * kc0, nz, lane);
+            wave_lds_sync();  // the previous chunk's readers are done
+            stage_store(s_z, zr, lane);
+            stage_store(s_v, vr, lane);
+            wave_lds_sync();
+        }
         // rows of I(15) on x_1 (src/constraints.jl:228), I(15)[1:14,:] on x_N (:229), final control (:259-260)
         if (first_chunk && lane < 15) Yb[lane] = s_v[lane];
         if (last_chunk) {
@@ -127,7 +145,7 @@ __global__ __launch_bounds__(kWave) void k_constraint_jvp(BatchParams P, const d
 __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const double* __restrict__ Z,
                                                          const double* __restrict__ L, double* __restrict__ G) {
     // s_l: multipliers of the dynamics rows of knots kc0-1 .. kc0+nk-1 (15 each; knot -1 = zeros)
-    __shared__ double s_z[kPZ + 1], s_l[15 * (kPC + 1)], s_g[20 * (kPC + 1)];
+    __shared__ double s_z[kStageRoom], s_l[15 * (kPC + 1)], s_g[20 * (kPC + 1)];
     const int lane = threadIdx.x;
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     if (b >= P.B) return;  // wave-uniform
@@ -144,13 +162,25 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
         const int nk = min(kPC, N - 1 - kc0);
         const int nz = 20 * nk + 15;
         const bool last_chunk = (kc0 + nk == N - 1);
-        wave_lds_sync();
-        stage(s_z, Zb + 20 * kc0, nz, lane);
-        for (int i = lane; i < 15 * (nk + 1); i += kWave) {
-            const int j = 15 * (kc0 - 1) + i;  // index into the dynamics rows
-            s_l[i] = (j >= 0) ? Lb[pv.o_dyn + j] : 0.0;
+        {
+            constexpr int kLamIters = (15 * (kPC + 1) + kWave - 1) / kWave;
+            double zr[kStageIters], lr[kLamIters];
+            stage_load(zr, Zb + 20 * kc0, nz, lane);
+            const int nl = 15 * (nk + 1);
+#pragma unroll
+            for (int it = 0; it < kLamIters; ++it) {
+                const int i = min(it * kWave + lane, nl - 1);
+                const int j = 15 * (kc0 - 1) + i;  // index into the dynamics rows; knot -1 has no multipliers
+                lr[it] = Lb[pv.o_dyn + max(j, 0)];
+                if (j < 0) lr[it] = 0.0;
+            }
+            wave_lds_sync();  // the previous chunk's readers are done
+            stage_store(s_z, zr, lane);
+#pragma unroll
+            for (int it = 0; it < kLamIters; ++it)
+                if (it * kWave + lane < 15 * (kPC + 1)) s_l[it * kWave + lane] = lr[it];
+            wave_lds_sync();
         }
-        wave_lds_sync();
         const bool valid = lane < nk;
         const bool own = valid || (last_chunk && lane == nk);
         const int kk = kc0 + lane, K = kk + 1;
@@ -235,7 +265,128 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // y = A v, all operands in LDS (z, v: layout of Z; y: layout of c; mask[k] = 1 if clearance row k is active)
-// (A D) v: the columns of A are scaled by dsc (0 = variable held fixed)
+// The step block of a knot does not change during a Gauss-Newton step, so when every lane owns at most one knot
+// (N <= 64) its 85 entries are computed once and kept in registers (170 VGPRs; the kernel runs one wave per SIMD
+// anyway, LDS being what limits residency): a product is then 85 fused multiply-adds per knot.
+struct KnotJac {
+    double e[kStepUnion];  // entries of the step block, column-major over the union pattern
+    double dth;            // d(clearance)/d(theta)
+};
+
+__device__ __forceinline__ void knot_jacobian(const ProblemView& pv, const ModelConst& M, const double* z, int lane,
+                                              KnotJac& J) {
+    const int N = pv.N, kt = pv.kt, im = pv.im;
+    const double g = M.g, mb = M.mb, mf = M.mf, lb = M.lb, Ib = M.Ib;
+    const int kk = lane, K = kk + 1;
+    const double* zk = z + 20 * (kk < N ? kk : 0);
+    J.dth = clearance_dtheta(zk[2], lb);
+    double x[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) x[i] = zk[i];
+    const double F1x = zk[15], F1y = zk[16], F2x = zk[17], F2y = zk[18], h = zk[19];  // (unused garbage for kk >= N-1)
+    const int mode = (K <= kt - 1) ? im : 3;
+    const bool jump = (K == kt - 1), f1free = (mode == 2), f2free = (mode == 1);
+    QLN_STEP_BASE();
+#define JW(row, col, val)                                \
+    {                                                    \
+        constexpr int pos_ = step_union_pos(row, col);   \
+        J.e[pos_] = (val);                               \
+    }
+    QLN_STEP_ENTRIES();
+#undef JW
+}
+
+// (A D) v with the lane's block in registers (N <= 64)
+__device__ __forceinline__ void lds_jvp_cached(const ProblemView& pv, const KnotJac& J, const double* v, const double* dsc,
+                                               const double* mask, double* y, int lane) {
+    const int N = pv.N, kt = pv.kt;
+    if (lane < 15) y[lane] = dsc[lane] * v[lane];
+    if (lane >= 15 && lane < 29) y[lane] = dsc[20 * (N - 1) + (lane - 15)] * v[20 * (N - 1) + (lane - 15)];
+    if (lane == 29)
+        y[pv.o_fc] = dsc[20 * (N - 2) + 16] * v[20 * (N - 2) + 16] + dsc[20 * (N - 2) + 18] * v[20 * (N - 2) + 18];
+    const int kk = lane, K = kk + 1;
+    const bool own = kk < N, valid = kk < N - 1;
+    const double* vk = v + 20 * (own ? kk : 0);
+    const double* dk = dsc + 20 * (own ? kk : 0);
+    if (own) {
+        const double v4 = dk[4] * vk[4], v6 = dk[6] * vk[6];
+        y[pv.o_ci + kk] = pv.init1 ? v4 : v6;
+        if (K >= kt) y[pv.o_co + (K - kt)] = pv.init1 ? v6 : v4;
+        y[pv.o_bp + kk] = mask[kk] * (dk[1] * vk[1] + J.dth * (dk[2] * vk[2]));
+    }
+    if (valid) {
+        double vin[20], acc[15];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) vin[i] = dk[i] * vk[i];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) acc[i] = 0.0;
+#define JW(row, col, val)                                \
+    {                                                    \
+        constexpr int pos_ = step_union_pos(row, col);   \
+        acc[row] += J.e[pos_] * vin[col];                \
+    }
+        QLN_STEP_ENTRIES();
+#undef JW
+#pragma unroll
+        for (int i = 0; i < 15; ++i) y[pv.o_dyn + 15 * kk + i] = acc[i] - dk[20 + i] * vk[20 + i];
+    }
+}
+
+// (A D)' lam with the lane's block in registers (N <= 64)
+__device__ __forceinline__ void lds_vjp_cached(const ProblemView& pv, const KnotJac& J, const double* lam, const double* dsc,
+                                               const double* mask, double* gz, int lane) {
+    const int N = pv.N, kt = pv.kt;
+    const int kk = lane, K = kk + 1;
+    const bool own = kk < N, valid = kk < N - 1;
+    double gk[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) gk[i] = 0.0;
+    if (valid) {
+        double l[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) l[i] = lam[pv.o_dyn + 15 * kk + i];
+#define JW(row, col, val)                                \
+    {                                                    \
+        constexpr int pos_ = step_union_pos(row, col);   \
+        gk[col] += J.e[pos_] * l[row];                   \
+    }
+        QLN_STEP_ENTRIES();
+#undef JW
+    }
+    if (own) {
+        if (kk >= 1) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) gk[i] -= lam[pv.o_dyn + 15 * (kk - 1) + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) gk[i] += lam[i];
+        }
+        if (kk == N - 1) {
+#pragma unroll
+            for (int i = 0; i < 14; ++i) gk[i] += lam[15 + i];
+        }
+        const double l_ci = lam[pv.o_ci + kk];
+        const double l_co = (K >= kt) ? lam[pv.o_co + (K - kt)] : 0.0;
+        gk[4] += pv.init1 ? l_ci : l_co;
+        gk[6] += pv.init1 ? l_co : l_ci;
+        if (kk == N - 2) {
+            const double l_fc = lam[pv.o_fc];
+            gk[16] += l_fc;
+            gk[18] += l_fc;
+        }
+        const double l_bp = mask[kk] * lam[pv.o_bp + kk];
+        gk[1] += l_bp;
+        gk[2] += J.dth * l_bp;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) gz[20 * kk + i] = dsc[20 * kk + i] * gk[i];
+        if (valid) {
+#pragma unroll
+            for (int i = 15; i < 20; ++i) gz[20 * kk + i] = dsc[20 * kk + i] * gk[i];
+        }
+    }
+}
+
+// (A D) v: the columns of A are scaled by dsc (0 = variable held fixed); every block re-derived from z (any N)
 __device__ __forceinline__ void lds_jvp(const ProblemView& pv, const ModelConst& M, const double* z, const double* v,
                                         const double* dsc, const double* mask, double* y, int lane) {
     const int N = pv.N, kt = pv.kt, im = pv.im;
@@ -344,6 +495,7 @@ __device__ __forceinline__ void lds_vjp(const ProblemView& pv, const ModelConst&
 
 // info[b][8] = {iterations, ||(AD)' rho||^2, ||(AD)'(A dZ + rho)||^2 at exit, ||A dZ + rho||^2 at exit, ||rho||^2,
 //              1 if the step was cut at the trust radius, ||D^-1 dZ||, 0}
+template <bool CACHED>
 __global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, const double* __restrict__ Z,
                                                                 const double* __restrict__ C, double* __restrict__ DZ,
                                                                 int max_iters, double rel_tol,
@@ -370,23 +522,59 @@ __global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, c
     double* mask = q + m;   // [N]  1 = clearance row active (violated)
     const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
     const double* __restrict__ Cb = C + pd.c_off;
-    for (int i = lane; i < n; i += kWave) {
-        z[i] = Zb[i];
-        x[i] = 0.0;
-        dsc[i] = col_scale ? col_scale[i] : 1.0;
+    // eight 512-byte loads in flight per round trip (clamped indices, predicated LDS writes)
+    constexpr int kU = 8;
+    for (int i0 = 0; i0 < n; i0 += kU * kWave) {
+        double zt[kU], dt[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = min(i0 + u * kWave + lane, n - 1);
+            zt[u] = Zb[i];
+            dt[u] = col_scale ? col_scale[i] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * kWave + lane;
+            if (i < n) {
+                z[i] = zt[u];
+                dsc[i] = dt[u];
+                x[i] = 0.0;
+            }
+        }
     }
     double phi0 = 0.0;
-    for (int i = lane; i < m; i += kWave) {
-        const double ci = Cb[i];
-        const bool ineq = i >= pv.o_bp;
-        const double rho = (ineq && !(ci < 0)) ? 0.0 : ci;  // a NaN in c propagates
-        r[i] = -rho;
-        phi0 += rho * rho;
-        if (ineq) mask[i - pv.o_bp] = (ci < 0 || ci != ci) ? 1.0 : 0.0;
+    for (int i0 = 0; i0 < m; i0 += kU * kWave) {
+        double ct[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) ct[u] = Cb[min(i0 + u * kWave + lane, m - 1)];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * kWave + lane;
+            if (i < m) {
+                const double ci = ct[u];
+                const bool ineq = i >= pv.o_bp;
+                const double rho = (ineq && !(ci < 0)) ? 0.0 : ci;  // a NaN in c propagates
+                r[i] = -rho;
+                phi0 += rho * rho;
+                if (ineq) mask[i - pv.o_bp] = (ci < 0 || ci != ci) ? 1.0 : 0.0;
+            }
+        }
     }
     phi0 = wave_sum(phi0);
     wave_lds_sync();
-    lds_vjp(pv, M, z, r, dsc, mask, s, lane);
+    KnotJac J;
+    if constexpr (CACHED) knot_jacobian(pv, M, z, lane, J);
+#define QLN_APPLY_A(v_, y_)                                               \
+    do {                                                                  \
+        if constexpr (CACHED) lds_jvp_cached(pv, J, v_, dsc, mask, y_, lane); \
+        else lds_jvp(pv, M, z, v_, dsc, mask, y_, lane);                  \
+    } while (0)
+#define QLN_APPLY_AT(l_, g_)                                              \
+    do {                                                                  \
+        if constexpr (CACHED) lds_vjp_cached(pv, J, l_, dsc, mask, g_, lane); \
+        else lds_vjp(pv, M, z, l_, dsc, mask, g_, lane);                  \
+    } while (0)
+    QLN_APPLY_AT(r, s);
     wave_lds_sync();
     double gamma = 0.0;
     for (int i = lane; i < n; i += kWave) {
@@ -402,7 +590,7 @@ __global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, c
     int it = 0;
     while (it < max_iters && gamma > rel_tol * rel_tol * gamma0) {  // wave-uniform; false for NaN
         wave_lds_sync();
-        lds_jvp(pv, M, z, p, dsc, mask, q, lane);
+        QLN_APPLY_A(p, q);
         wave_lds_sync();
         double qq = 0.0;
         for (int i = lane; i < m; i += kWave) qq += q[i] * q[i];
@@ -428,7 +616,7 @@ __global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, c
         for (int i = lane; i < n; i += kWave) x[i] += alpha * p[i];
         for (int i = lane; i < m; i += kWave) r[i] -= alpha * q[i];
         wave_lds_sync();
-        lds_vjp(pv, M, z, r, dsc, mask, s, lane);
+        QLN_APPLY_AT(r, s);
         wave_lds_sync();
         double gnew = 0.0;
         for (int i = lane; i < n; i += kWave) gnew += s[i] * s[i];
@@ -447,6 +635,8 @@ __global__ __launch_bounds__(kWave, 1) void k_gauss_newton_step(BatchParams P, c
     xn = wave_sum(xn);
     double* __restrict__ Db = DZ + (int64_t)b * P.z_stride;
     for (int i = lane; i < n; i += kWave) Db[i] = dsc[i] * x[i];
+#undef QLN_APPLY_A
+#undef QLN_APPLY_AT
     if (info && lane == 0) {
         double* o = info + 8 * (int64_t)b;
         o[0] = (double)it;
@@ -479,12 +669,16 @@ hipError_t launch_gauss_newton_step(const BatchParams& p, const double* Z, const
                                     double rel_tol, const double* radius, const double* col_scale, double* info,
                                     hipStream_t stream) {
     const size_t lds = gauss_newton_lds_bytes(p.N);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss_newton_step),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gauss_newton_step, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, Z, c, dZ, max_iters, rel_tol,
-                       radius, col_scale, info);
-    return hipGetLastError();
+    auto go = [&](auto kernel) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, Z, c, dZ, max_iters, rel_tol, radius,
+                           col_scale, info);
+        return hipGetLastError();
+    };
+    // one knot per lane: the step blocks stay in registers for the whole step
+    return (p.N <= kWave) ? go(k_gauss_newton_step<true>) : go(k_gauss_newton_step<false>);
 }
 
 }  // namespace qln
