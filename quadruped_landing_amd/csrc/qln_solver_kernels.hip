@@ -13,7 +13,7 @@
 // dynamics knots so that lane nk is free for the knot behind the chunk (the terminal knot x_N in the last one).
 #include "qln_kernel_common.h"
 
-// Nothing here has to round like the reference (the products are compared with the oracle to 1e-8), so a*b+c may fuse.
+// Nothing here has to round like the reference (the parity tests hold these kernels to 1e-8), so a*b+c may fuse.
 #pragma clang fp contract(fast)
 
 namespace qln {
