@@ -165,7 +165,9 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 //      residual stage alias the tile, so KC*35+16 doubles must fit in T*300
 // W  = waves per SIMD the register budget is sized for (LDS admits 160 KiB / tile per CU)
 // NNZ = structural format (QLN_JAC_FORMAT_STRUCTURAL): T is unused, the tile holds the chunk's KC compact blocks
-template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false>
+// SPLIT = small batches: one workgroup per CHUNK of KC knots instead of per problem, so that a batch with fewer
+//         problems than the chip has SIMDs still fills it (the launch is then as long as one chunk, not one problem)
+template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false, bool SPLIT = false>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
                                                               double* __restrict__ V, uint32_t flags) {
@@ -186,11 +188,15 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     double* const s_c = s_j + kCStage;
 
     const int lane = threadIdx.x;
-    const int bl = xcd_contiguous_index(blockIdx.x, nb);
-    if (bl >= nb) return;  // wave-uniform
+    const int cpp = SPLIT ? (P.N - 2) / KC + 1 : 1;  // chunks (= workgroups) per problem
+    const int vi = xcd_contiguous_index(blockIdx.x, nb * cpp);
+    if (vi >= nb * cpp) return;  // wave-uniform
+    const int bl = SPLIT ? vi / cpp : vi;
     const int b = b_begin + bl;
     QLN_STAMP(0);
     const int N = P.N;
+    const int kc_begin = SPLIT ? (vi - bl * cpp) * KC : 0;      // the dynamics knots this workgroup owns
+    const int kc_end = SPLIT ? min(kc_begin + KC, N - 1) : N - 1;
     const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
 
     // The first chunk's slice of Z (and the boundary vectors for c1/c2) depends only on the kernel
@@ -202,9 +208,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     double zr[kStageIters];
     double bnd = 0.0;
     {
-        const int nz0 = 20 * min(KC, N - 1) + 15;
+        const int nz0 = 20 * min(KC, N - 1 - kc_begin) + 15;
 #pragma unroll
-        for (int it = 0; it < kStageIters; ++it) zr[it] = Zb[min(it * kWave + lane, nz0 - 1)];
+        for (int it = 0; it < kStageIters; ++it) zr[it] = Zb[20 * kc_begin + min(it * kWave + lane, nz0 - 1)];
         if (WITH_C) {
             // x0 / xf for c1 / c2 (src/constraints.jl:149-150): unconditional and in bounds
             bnd = P.bnd[(int64_t)b * 30 + min(lane, 29)];  // x0[lane] for lane < 15, xf[lane - 15] after
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     // length of the step-block section of vals
     const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
 
-    if (WITH_J && (flags & 1u)) {
+    if (WITH_J && (flags & 1u) && kc_begin == 0) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
         double* Vc = Vb + dyn_blocks + N;
         const int n_const = 435 + 15 * (N - 1) + 3 * N - kt + 3;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
         }
     }
 
-    for (int kc0 = 0; kc0 < N - 1; kc0 += KC) {
+    for (int kc0 = kc_begin; kc0 < kc_end; kc0 += KC) {
         const int nk = min(KC, N - 1 - kc0);
         const int nz = 20 * nk + 15;
         const bool first_chunk = (kc0 == 0);
@@ -267,9 +273,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
         const bool f2free = (mode == 1);
         const double* zl = s_z + 20 * (valid ? lane : 0);
 
-        // ---- stage the chunk's slice of Z through LDS (chunk 0 was requested at kernel entry) ----
+        // ---- stage the chunk's slice of Z through LDS (the first one was requested at kernel entry) ----
         {
-            if (!first_chunk) {
+            if (kc0 != kc_begin) {
                 const double* __restrict__ zsrc = Zb + 20 * kc0;
 #pragma unroll
                 for (int it = 0; it < kStageIters; ++it) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
@@ -743,10 +749,10 @@ __global__ __launch_bounds__(256) void k_lqr_cost(BatchParams P, const double* _
     out[40] = a + bb;                                      // c = 0.5*xf'Q*xf + 0.5*uf'R*uf
 }
 
-template <int T, int KC, int W, bool NNZ = false>
+template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
-    dim3 grid(xcd_grid(nb)), block(kWave);
+    dim3 grid(xcd_grid(SPLIT ? nb * ((p.N - 2) / KC + 1) : nb)), block(kWave);
 #ifdef QLN_TUNING
     // tuning build only: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
@@ -757,11 +763,11 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
     constexpr unsigned pad = 0;
 #endif
     if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, NNZ>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, NNZ, SPLIT>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
     else if (c)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, NNZ>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, NNZ, SPLIT>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     else
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true, NNZ>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true, NNZ, SPLIT>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
     return hipGetLastError();
 }
 
@@ -789,6 +795,14 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 1: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 2: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        default: break;
+    }
+    switch (variant) {  // small-batch launches: one workgroup per chunk
+        case 21: if (p.jac_format == QLN_JAC_FORMAT_DENSE_BLOCKS) return launch_cj_t<16, 16, 1, false, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
+        case 22: if (p.jac_format == QLN_JAC_FORMAT_DENSE_BLOCKS) return launch_cj_t<8, 8, 2, false, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
+        case 23: if (p.jac_format == QLN_JAC_FORMAT_DENSE_BLOCKS) return launch_cj_t<10, 10, 2, false, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
+        case 24: if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL && vals) return launch_cj_t<0, 16, 2, true, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
+        case 25: if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL && vals) return launch_cj_t<0, 8, 2, true, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
         default: break;
     }
     if (vals && p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) switch (variant) {
