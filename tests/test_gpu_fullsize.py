@@ -116,3 +116,62 @@ def test_permutation_equivariance():
     for i in (0, 1, 17, 4095):
         assert np.array_equal(n1.split_c(c1, i), n0.split_c(c0, perm[i]))
         assert np.array_equal(n1.split_vals(v1, i), n0.split_vals(v0, perm[i]))
+
+
+def test_full_size_structural_format_and_products_agree_with_the_dense_blocks():
+    """B = 65 536, N = 40 (BASELINE.json configs[2]), every problem: (1) the structural format holds bitwise the
+    entries of the dense blocks at the positions qln_jacobian_structure lists, and nothing it leaves out is non-zero;
+    (2) J v and J' lam (Jacobian re-derived in registers) equal the products formed from the evaluator's own stored
+    Jacobian values."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    B, N = 65536, 40
+    batch = PG.make_batch(B, N, 14, 1, seed=3)
+    mk = lambda fmt: HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                               stream=torch.cuda.current_stream(), jac_format=fmt)
+    nd, ns = mk("dense_blocks"), mk("structural")
+    Z = nd.upload_Z(batch.Z)
+    cd, vd = nd.eval_c_and_jac(Z, write_constants=True)
+    cs, vs = ns.eval_c_and_jac(Z, write_constants=True)
+    torch.cuda.synchronize()
+    assert torch.equal(cd, cs)
+
+    def per_problem(nlp, vals):
+        stride = int(nlp.j_off[1] - nlp.j_off[0])
+        nnz = nlp.problem_dims(0)[1]
+        # the last problem's segment is not padded to the stride: view the first B-1 problems as a matrix
+        return vals[: (B - 1) * stride].view(B - 1, stride)[:, :nnz], nnz
+
+    Vd, nnz_d = per_problem(nd, vd)
+    Vs, nnz_s = per_problem(ns, vs)
+    rd, cd_ = nd.jacobian_structure(0)
+    rs, cs_ = ns.jacobian_structure(0)
+    n, m = nd.n_nlp, nd.problem_dims(0)[0]
+    pos_d = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(rd, cd_))}
+    idx = torch.tensor([pos_d[(int(r), int(c))] for r, c in zip(rs, cs_)], device="cuda")
+    assert torch.equal(Vd[:, idx], Vs)                                  # (1) same values, bitwise, for 65 535 problems
+    left_out = torch.ones(nnz_d, dtype=torch.bool, device="cuda")
+    left_out[idx] = False
+    assert int((Vd[:, left_out] != 0).sum()) == 0                       #     and only zeros are left out
+
+    # (2) products against the stored Jacobian, all problems at once
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    v = torch.randn(nd.dims.z_total, dtype=torch.float64, device="cuda", generator=gen)
+    lam = torch.randn(nd.dims.c_total, dtype=torch.float64, device="cuda", generator=gen)
+    y, g = ns.jac_vec(Z, v), ns.jac_t_vec(Z, lam)
+    torch.cuda.synchronize()
+    rows = torch.from_numpy(rs.astype(np.int64)).cuda()
+    cols = torch.from_numpy(cs_.astype(np.int64)).cuda()
+    cstride = int(nd.c_off[1] - nd.c_off[0])
+    Vm = v.view(B, -1)[: B - 1, :n]
+    Lm = lam[: (B - 1) * cstride].view(B - 1, cstride)[:, :m]
+    y_ref = torch.zeros(B - 1, m, dtype=torch.float64, device="cuda").index_add_(1, rows, Vs * Vm[:, cols])
+    y_abs = torch.zeros_like(y_ref).index_add_(1, rows, (Vs * Vm[:, cols]).abs())
+    ey = ((y[: (B - 1) * cstride].view(B - 1, cstride)[:, :m] - y_ref).abs() / y_abs.clamp_min(1e-300)).max().item()
+    del y_ref, y_abs
+    g_ref = torch.zeros(B - 1, n, dtype=torch.float64, device="cuda").index_add_(1, cols, Vs * Lm[:, rows])
+    g_abs = torch.zeros_like(g_ref).index_add_(1, cols, (Vs * Lm[:, rows]).abs())
+    eg = ((g.view(B, -1)[: B - 1, :n] - g_ref).abs() / g_abs.clamp_min(1e-300)).max().item()
+    print(f"full size: J v vs stored J: {ey:.3e}, J' lam vs stored J: {eg:.3e} (relative to sum |J||v|)")
+    assert ey <= 1e-12 and eg <= 1e-12
