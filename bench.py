@@ -245,7 +245,7 @@ def main():
         if world == 1 and not args.no_other and not structural:
             # same workload, structural format (only the non-zeros of every step block are written)
             del vals
-            bs, ns, Zs, cs, vs = build(args.workload, seed=rank, device=local_rank, placement_trials=1, jac_format="structural")
+            bs, ns, Zs, cs, vs = build(args.workload, seed=rank, device=local_rank, placement_trials=min(2, args.placement_trials), jac_format="structural")
             mss = ns.time_c_and_jac(Zs, cs, vs, warmup=5, iters=K)
             sb = float(np.sum(strict_bytes(bs.N, bs.k_trans)))
             out.setdefault("other", {})["structural_format"] = {

@@ -126,6 +126,11 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `make -C quadruped_landing_amd/csrc` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        # The process must hold ONE HIP runtime: PyTorch-ROCm ships its own libamdhip64 and the handle's buffers are
+        # torch tensors, so torch's copy is loaded first and libqln_hip.so binds to it (loading this library before
+        # torch would bring in /opt/rocm's copy, and the second runtime to initialise then sees no device).
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
