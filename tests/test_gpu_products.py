@@ -127,3 +127,18 @@ def test_adjoint_identity_at_full_batch_size():
     err = ((yl - vg).abs() / scale).max().item()
     print(f"adjoint identity over {nb} problems: max |<Jv,l> - <v,J'l>| / sum|Jv||l| = {err:.3e}")
     assert err <= 1e-12
+
+
+def test_products_random_shapes_and_layouts_property():
+    """Randomised shapes/layouts (hypothesis) for J v and J' lam."""
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import problem_gen as PG
+
+    @settings(max_examples=15, deadline=None)
+    @given(B=st.integers(1, 24), N=st.integers(2, 200), pad=st.integers(0, 9), align=st.sampled_from([1, 2, 3, 16, 32]),
+           seed=st.integers(0, 10**6))
+    def check(B, N, pad, align, seed):
+        batch = PG.make_batch(B, N, seed=seed, ragged=True) if N > 3 else PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        _check_products(batch, seed=seed, z_stride=(20 * N - 5 + pad) if pad else 0, align=align)
+
+    check()

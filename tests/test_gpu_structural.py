@@ -176,3 +176,19 @@ def test_structural_dense_host_scatter_is_the_reference_write_set():
         assert np.array_equal(np.isnan(D), np.isnan(Dref))
         assert rel_err(D, Dref, floor=1e-300) <= RTOL
         assert np.array_equal(D == 0, Dref == 0)
+
+
+def test_structural_random_shapes_and_layouts_property():
+    """Randomised shapes/layouts (hypothesis): any B, N (one to three chunks of the kernel), per-problem k_trans /
+    init_mode, Z stride and offset alignment -- the structural format stays bitwise the dense blocks' entries."""
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import problem_gen as PG
+
+    @settings(max_examples=15, deadline=None)
+    @given(B=st.integers(1, 24), N=st.integers(2, 130), pad=st.integers(0, 9), align=st.sampled_from([1, 2, 3, 16, 32]),
+           seed=st.integers(0, 10**6))
+    def check(B, N, pad, align, seed):
+        batch = PG.make_batch(B, N, seed=seed, ragged=True) if N > 3 else PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        _check(batch, z_stride=(20 * N - 5 + pad) if pad else 0, align=align)
+
+    check()
