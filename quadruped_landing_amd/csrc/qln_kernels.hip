@@ -554,10 +554,12 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
     // Lane = entry of Z for the products (coalesced reads of Z and of the [k][41] cost records), lane = knot for
     // the reference's left-to-right sums (src/quadratic_cost.jl:44-52), lane 0 for the sequential sum over knots
     // (src/costs.jl:9-15): every floating-point operation and its order is the reference's, so f is bit-identical.
-    constexpr int kKnots = 32;                       // knots per pass
+    // A pass covers 64 knots (1280 entries of Z = 20 loads per lane, all in flight before the first wait).
+    constexpr int kKnots = kWave;                    // knots per pass
+    constexpr int kIters = kKnots * 20 / kWave;      // entries per lane and pass
     __shared__ double s_quad[kKnots * 20];           // (0.5 * (D_i * z_i)) * z_i
     __shared__ double s_lin[kKnots * 20];            // d_i * z_i
-    __shared__ double s_h[kKnots];
+    __shared__ double s_h[kKnots];                   // h_k = u_k[5]
     __shared__ double s_term[kKnots];
     const int lane = threadIdx.x;
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
@@ -569,69 +571,108 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
     for (int k0 = 0; k0 < N; k0 += kKnots) {
         const int nk = min(kKnots, N - k0);
         const int ne = min(20 * nk, 20 * N - 5 - 20 * k0);  // entries of Z in this pass (x_N has no controls)
-        __syncthreads();
+        double z[kIters], D[kIters], d[kIters];
 #pragma unroll
-        for (int it = 0; it < kKnots * 20 / kWave; ++it) {
-            const int e = it * kWave + lane;
-            if (e < ne) {
-                const int kk = e / 20, j = e - 20 * kk;
-                const double z = Zb[20 * k0 + e];
-                const double* ck = cost + (int64_t)(k0 + kk) * 41;
-                s_quad[e] = (0.5 * (ck[j] * z)) * z;     // Q or R slot j
-                s_lin[e] = ck[20 + j] * z;               // q or r slot j
-                if (j == 19) s_h[kk] = z;
-            }
+        for (int it = 0; it < kIters; ++it) {
+            const int e = min(it * kWave + lane, ne - 1);   // clamped, not predicated
+            const int kk = e / 20, j = e - 20 * kk;
+            const double* ck = cost + (int64_t)(k0 + kk) * 41;
+            z[it] = Zb[20 * k0 + e];
+            D[it] = ck[j];                                   // Q or R slot j
+            d[it] = ck[20 + j];                              // q or r slot j
         }
-        __syncthreads();
-        if (lane < nk) {
-            const int k = k0 + lane;
-            const double* q = s_quad + 20 * lane;
-            const double* l = s_lin + 20 * lane;
+        const double ck40 = cost[(int64_t)(k0 + min(lane, nk - 1)) * 41 + 40];
+        wave_lds_sync();  // the previous pass's readers are done
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int e = it * kWave + lane;
+            s_quad[e] = (0.5 * (D[it] * z[it])) * z[it];
+            s_lin[e] = d[it] * z[it];
+            const int kk = e / 20;
+            if (e - 20 * kk == 19 && e < ne) s_h[kk] = z[it];
+        }
+        wave_lds_sync();
+        {
+            const int kl = min(lane, nk - 1);
+            const int k = k0 + kl;
+            const double* q = s_quad + 20 * kl;
+            const double* l = s_lin + 20 * kl;
             double a = q[0], bb = l[0];
 #pragma unroll
             for (int i = 1; i < 15; ++i) {
                 a = a + q[i];
                 bb = bb + l[i];
             }
-            const double ck40 = cost[(int64_t)k * 41 + 40];
             double term;
             if (k < N - 1) {
-                double cc = q[15], d = l[15];
+                double cc = q[15], dd = l[15];
 #pragma unroll
                 for (int i = 16; i < 20; ++i) {
                     cc = cc + q[i];
-                    d = d + l[i];
+                    dd = dd + l[i];
                 }
-                term = s_h[lane] * ((((a + bb) + cc) + d) + ck40);  // hk * stagecost
+                term = s_h[kl] * ((((a + bb) + cc) + dd) + ck40);  // hk * stagecost
             } else {
                 term = (a + bb) + ck40;                             // termcost
             }
-            s_term[lane] = term;
+            s_term[lane] = (lane < nk) ? term : 0.0;
         }
-        __syncthreads();
-        if (lane == 0)
-            for (int i = 0; i < nk; ++i) J += s_term[i];
+        wave_lds_sync();
+        // J += term_k for k in order; the lanes past nk hold 0.0 and J + 0.0 == J
+        double t[kKnots];
+#pragma unroll
+        for (int i = 0; i < kKnots; ++i) t[i] = s_term[i];
+#pragma unroll
+        for (int i = 0; i < kKnots; ++i) J += t[i];
     }
     if (lane == 0) F[b] = J;
 }
 
-// Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  One workgroup per problem.
+// Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  Flat over the entries of the whole batch
+// (a problem's 20N-5 entries do not fill whole workgroups): 1024 consecutive entries per workgroup, four per thread,
+// loads issued before the first store.
 __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const double* __restrict__ Z,
-                                                           double* __restrict__ G) {
+                                                           double* __restrict__ G, int64_t total, int ntiles) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
-    const int b = xcd_contiguous_index(blockIdx.x, P.B);
-    if (b >= P.B) return;
-    const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
-    double* __restrict__ Gb = G + (int64_t)b * P.z_stride;
-    const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
-    for (int i = threadIdx.x; i < n_nlp; i += blockDim.x) {
+    const int tile = xcd_contiguous_index(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    constexpr int kU = 4;
+    double z[kU], D[kU], d[kU], h[kU];
+    int64_t at[kU];
+    bool stage[kU];
+    // (problem, entry) of the thread's first element by one division, of the next ones by stepping
+    const int64_t e0 = (int64_t)tile * (kU * 256) + (int)threadIdx.x;
+    const int b0 = (int)(e0 / n_nlp);
+    const int i0 = (int)(e0 - (int64_t)b0 * n_nlp);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        int b = b0, i = i0 + u * 256;
+        while (i >= n_nlp) {
+            i -= n_nlp;
+            ++b;
+        }
+        if (b >= P.B) {  // past the end of the batch: clamp to the last entry (the store below is predicated)
+            b = P.B - 1;
+            i = n_nlp - 1;
+        }
         const int k = i / 20, j = i - 20 * k;
-        const double* ck = cost + (int64_t)k * 41;
-        const double z = Zb[i];
-        // Q*x + q for j < 15, R*u + r for the controls: record slots [0,20) and [20,40)
-        const double lin = ck[j] * z + ck[20 + j];
-        Gb[i] = (k < N - 1) ? Zb[20 * k + 19] * lin : lin;
+        const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
+        const double* ck = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0) + (int64_t)k * 41;
+        at[u] = (int64_t)b * P.z_stride + i;
+        stage[u] = k < N - 1;
+        z[u] = Zb[i];
+        D[u] = ck[j];        // Q*x + q for j < 15, R*u + r for the controls: record slots [0,20) and [20,40)
+        d[u] = ck[20 + j];
+        h[u] = Zb[min(20 * k + 19, n_nlp - 1)];  // h_k; not used for the terminal knot
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int64_t e = (int64_t)tile * (kU * 256) + u * 256 + (int)threadIdx.x;
+        if (e < total) {
+            const double lin = D[u] * z[u] + d[u];
+            G[at[u]] = stage[u] ? h[u] * lin : lin;
+        }
     }
 }
 
@@ -850,7 +891,9 @@ hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t str
 }
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
-    hipLaunchKernelGGL(k_objective_gradient, dim3(xcd_grid(p.B)), dim3(256), 0, stream, p, Z, grad);
+    const int64_t total = (int64_t)p.B * (20 * p.N - 5);
+    const int ntiles = (int)((total + 1023) / 1024);
+    hipLaunchKernelGGL(k_objective_gradient, dim3(xcd_grid(ntiles)), dim3(256), 0, stream, p, Z, grad, total, ntiles);
     return hipGetLastError();
 }
 
