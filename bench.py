@@ -129,6 +129,13 @@ def main():
                     help="candidate allocations of the Jacobian buffer tried at setup (1 = take the first)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
+    # fd 1 when the process group is created), so everything that is not the result goes to stderr: fd 1 is pointed at
+    # stderr for the duration of the run and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from quadruped_landing_amd import distributed as D
@@ -270,7 +277,8 @@ def main():
             one, allc = cpu_baseline(batch, nlp)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
