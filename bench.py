@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--jac-format", default="dense_blocks", choices=["dense_blocks", "structural"],
                     help="layout of the step blocks in vals: the reference's dense 15x20 blocks (the unit SURVEY.md 8d "
                          "prices) or only their structurally non-zero entries (priced at the strict byte count)")
-    ap.add_argument("--placement-trials", type=int, default=4,
+    ap.add_argument("--placement-trials", type=int, default=8,
                     help="candidate allocations of the Jacobian buffer tried at setup (1 = take the first)")
     args = ap.parse_args()
 
