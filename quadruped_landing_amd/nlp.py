@@ -228,26 +228,38 @@ class HybridNLP:
     def new_vals(self):
         return _torch().zeros(self.dims.j_total, dtype=_torch().float64, device=self._dev())
 
-    def new_vals_placed(self, Z, c, trials: int = 4, launches: int = 3):
+    def new_vals_placed(self, Z, c, trials: int = 4, launches: int = 3, spread: bool = True):
         """Setup-time placement choice for the (large, long-lived) Jacobian buffer.
 
         Where the driver places a multi-GB allocation physically changes the sustained store bandwidth of
         the hot kernel by up to ~20 % on MI355X (profiles/r01_placement_sensitivity.txt),
-        and an allocation keeps its placement for its lifetime.  This allocates `trials` candidate buffers
-        (held simultaneously, so the driver cannot hand the same pages back), times `launches` launches of the
-        fused kernel on each, keeps the fastest and frees the others.  Returns (vals, [ms per trial]).
+        and an allocation keeps its placement for its lifetime.  The speed class is a property of the REGION of
+        device memory: consecutive allocations share it in runs of ~32 GiB (profiles/r01_placement_windows.txt).
+        This allocates `trials` candidate buffers, held simultaneously and -- with `spread` -- separated by
+        spacer allocations so that they sample different regions, times `launches` launches of the fused kernel
+        on each, keeps the fastest and frees everything else.  Returns (vals, [ms per trial]).
         """
         t = _torch()
-        cands, times = [], []
-        for _ in range(max(1, int(trials))):
+        trials = max(1, int(trials))
+        nbytes = 8 * int(self.dims.j_total)
+        spacer_bytes = 0
+        if spread and trials > 1:
+            free, _ = t.cuda.mem_get_info(self._dev())
+            # one candidate + one spacer per trial, about 32 GiB apart, within 85 % of what is free now
+            spacer_bytes = max(0, min(32 * 2**30 - nbytes, int(0.85 * free) // trials - nbytes))
+        cands, times, spacers = [], [], []
+        for i in range(trials):
             v = self.new_vals()
             self.init_jacobian_constants(v)
             ms = self.time_c_and_jac(Z, c, v, warmup=1, iters=max(1, int(launches)))
             cands.append(v)
             times.append(float(np.median(ms)))
+            if spacer_bytes >= 2**20 and i + 1 < trials:
+                spacers.append(t.empty(spacer_bytes, dtype=t.uint8, device=self._dev()))
         best = int(np.argmin(times))
         vals = cands[best]
         cands.clear()
+        spacers.clear()
         del v
         t.cuda.empty_cache()
         return vals, times
