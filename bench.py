@@ -14,7 +14,6 @@ of the full constraint vectors (379 MB per rank) is timed once outside the regio
 `gather_c_ms`; Jacobian values stay resident on the GPU that produced them.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys

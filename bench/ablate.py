@@ -1,9 +1,9 @@
 """Measurement aid: time the separate entry points on the bench workload (not part of the product)."""
-import os, sys, time
+import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bench import build, WORKLOADS
+from bench import build
 
 def t_ms(fn, iters=20):
     for _ in range(3): fn()

@@ -7,7 +7,7 @@ Backend-agnostic (`nccl` = RCCL on the GPUs, `gloo` on CPU for the tests).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 
 def shard_range(n_problems: int, rank: int, world_size: int) -> Tuple[int, int]:

@@ -8,7 +8,6 @@ include/qln_evaluator.h -- there is no CPU implementation of the arithmetic here
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
 
 import numpy as np
 
