@@ -17,8 +17,9 @@
  *
  * Threading: a handle is not thread-safe; distinct handles are independent.  Batched (device-pointer)
  * calls are asynchronous and ordered on the handle's stream; MOI-mode (host-pointer) calls return
- * after the results are in the caller's buffers.  The library never allocates, frees or keeps caller
- * buffers; it owns only its handle (descriptor copies and, for MOI mode, lazily allocated staging).
+ * after the results are in the caller's buffers.  The library never frees, reallocates or keeps caller
+ * buffers; it owns only its handle (descriptor copies and, for MOI mode, lazily allocated staging) and what the
+ * caller explicitly asks it to allocate with qln_vals_alloc_placed.
  *
  * Layouts (all FP64, all offsets/strides in doubles):
  *   Z     problem b at Z + b*z_stride, length n_nlp = 20N-5,
@@ -196,6 +197,20 @@ int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* va
  * column-major m_nlp x n_nlp buffer; exactly the jac_c! write-set is assigned (explicit zeros of
  * the identity blocks included), every other entry is left untouched.  `b` selects the problem. */
 int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const double* Z, double* jac);
+
+/* Placement-aware allocation of the Jacobian buffer (optional; every entry point also accepts plain hipMalloc memory).
+ * On MI355X the store bandwidth a buffer sustains depends on where it lies physically: device memory behaves as 32-GiB
+ * regions, and the evaluator's eight write fronts (one per XCD, the first four in the first half of vals) run ~20 %
+ * faster when the two halves of the buffer lie in different regions (DESIGN.md section 5,
+ * profiles/r01_placement_windows.txt).  This call builds such a buffer with the HIP virtual-memory API: it maps
+ * j_total doubles + 32 GiB of physical memory in 256-MiB chunks behind one virtual range, times the fused launch
+ * (Z, c as for qln_eval_constraint_and_jacobian; c is overwritten) on windows of that range, keeps the fastest window
+ * and returns every chunk outside it to the driver.  *vals is at least 2-MiB aligned and holds j_total doubles; constants are
+ * not written.  ms_best (may be NULL): launch time on the window kept.  Needs j_total*8 + ~33 GiB of free device
+ * memory for the duration of the call; QLN_ERR_HIP if that (or the virtual-memory API) is not available.
+ * Release with qln_vals_free_placed (qln_destroy releases what is left). */
+int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best);
+int qln_vals_free_placed(qln_handle* h, double* vals);
 
 /* Measurement helper for bench.py: runs `warmup` + `iters` launches of the fused hot path on the
  * handle's stream and returns each timed launch's duration from HIP events (milliseconds). */

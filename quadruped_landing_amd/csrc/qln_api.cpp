@@ -72,6 +72,16 @@ struct qln_handle {
     double* s_f = nullptr;
     double* s_grad = nullptr;
     std::vector<double> h_vals_one;
+    // buffers handed out by qln_vals_alloc_placed
+    struct Placed {
+        char* va = nullptr;        // reserved virtual range
+        size_t va_size = 0;
+        size_t chunk = 0;
+        size_t first = 0;          // first chunk still mapped
+        std::vector<hipMemGenericAllocationHandle_t> chunks;  // the mapped ones, in order
+        double* vals = nullptr;
+    };
+    std::vector<Placed> placed;
 };
 
 namespace {
@@ -210,9 +220,20 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     return QLN_OK;
 }
 
+static void release_placed(qln_handle::Placed& p) {
+    for (size_t i = 0; i < p.chunks.size(); ++i) {
+        (void)hipMemUnmap(p.va + (p.first + i) * p.chunk, p.chunk);
+        (void)hipMemRelease(p.chunks[i]);
+    }
+    p.chunks.clear();
+    if (p.va) (void)hipMemAddressFree(p.va, p.va_size);
+    p.va = nullptr;
+}
+
 int qln_destroy(qln_handle* h) {
     if (!h) return QLN_OK;
     (void)hipSetDevice(h->device);
+    for (auto& p : h->placed) release_placed(p);
     void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -573,6 +594,141 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
     const double* v = h->h_vals_one.data();
     for (int32_t e = 0; e < nnz; ++e) jac[rows[e] + m * (int64_t)cols[e]] = v[e];
     return QLN_OK;
+}
+
+// ------------------------------------------------------------------ placement-aware allocation
+
+static int time_fused(qln_handle* h, const double* Z, double* c, double* vals, int warmup, int iters, float* best) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(QLN_ERR_HIP, "hipEventCreate failed");
+    }
+    int rc = QLN_OK;
+    *best = 1e30f;
+    for (int i = 0; i < warmup + iters && rc == QLN_OK; ++i) {
+        (void)hipEventRecord(e0, h->stream);
+        if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, 0, h->stream) != hipSuccess) rc = fail(QLN_ERR_HIP, "launch failed");
+        (void)hipEventRecord(e1, h->stream);
+        if (rc == QLN_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventSynchronize failed");
+        float ms = 0.f;
+        if (rc == QLN_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
+        if (rc == QLN_OK && i >= warmup) *best = std::min(*best, ms);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_alloc_placed: null pointer");
+    *vals = nullptr;
+    if (int rc = bind_device(h)) return rc;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    size_t gran = 0;
+    QLN_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    const size_t chunk = round_up((int64_t)256 << 20, (int64_t)gran);   // physical chunks; 2 GiB and more fault on ROCm 7.2
+    const size_t region = (size_t)32 << 30;                              // period of the speed classes
+    const size_t need = (size_t)round_up(h->dims.j_total * 8, (int64_t)chunk);
+    size_t free_b = 0, total_b = 0;
+    QLN_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t span = need + region + chunk;
+    if (span > free_b / 10 * 9) span = free_b / 10 * 9 / chunk * chunk;
+    if (span < need + chunk) return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: not enough free device memory");
+    const size_t nchunks = span / chunk;
+
+    qln_handle::Placed P;
+    P.chunk = chunk;
+    P.va_size = nchunks * chunk;
+    void* va = nullptr;
+    QLN_HIP(hipMemAddressReserve(&va, P.va_size, 0, nullptr, 0));
+    P.va = static_cast<char*>(va);
+    auto bail = [&](const std::string& what, hipError_t e) {
+        release_placed(P);
+        return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: " + what + ": " + hipGetErrorString(e));
+    };
+    for (size_t i = 0; i < nchunks; ++i) {
+        hipMemGenericAllocationHandle_t hd;
+        hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
+        if (e != hipSuccess) return bail("hipMemCreate", e);
+        e = hipMemMap(P.va + i * chunk, chunk, 0, hd, 0);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(hd);
+            return bail("hipMemMap", e);
+        }
+        P.chunks.push_back(hd);
+    }
+    hipMemAccessDesc ad = {};
+    ad.location = prop.location;
+    ad.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipError_t e = hipMemSetAccess(P.va, P.va_size, &ad, 1); e != hipSuccess) return bail("hipMemSetAccess", e);
+
+    // coarse scan (1-GiB steps), then 256-MiB steps around the best window
+    const size_t last = P.va_size - need;
+    size_t best_off = 0;
+    float best = 1e30f;
+    auto probe = [&](size_t off) {
+        float ms = 0.f;
+        const int rc = time_fused(h, Z, c, reinterpret_cast<double*>(P.va + off), 1, 2, &ms);
+        if (rc == QLN_OK && ms < best) {
+            best = ms;
+            best_off = off;
+        }
+        return rc;
+    };
+    const size_t coarse = (size_t)1 << 30;
+    for (size_t off = 0; off <= last; off += coarse)
+        if (int rc = probe(off)) {
+            release_placed(P);
+            return rc;
+        }
+    {
+        const size_t centre = best_off;
+        for (int k = -3; k <= 3; ++k) {
+            if (k == 0) continue;
+            const int64_t off = (int64_t)centre + (int64_t)k * (int64_t)chunk;
+            if (off < 0 || (size_t)off > last) continue;
+            if (int rc = probe((size_t)off)) {
+                release_placed(P);
+                return rc;
+            }
+        }
+    }
+    // keep the chunks under the window, give the rest back
+    const size_t c0 = best_off / chunk, c1 = (best_off + need) / chunk;  // [c0, c1)
+    std::vector<hipMemGenericAllocationHandle_t> keep;
+    for (size_t i = 0; i < P.chunks.size(); ++i) {
+        if (i >= c0 && i < c1) {
+            keep.push_back(P.chunks[i]);
+        } else {
+            (void)hipMemUnmap(P.va + i * chunk, chunk);
+            (void)hipMemRelease(P.chunks[i]);
+        }
+    }
+    P.chunks.swap(keep);
+    P.first = c0;
+    P.vals = reinterpret_cast<double*>(P.va + best_off);
+    h->placed.push_back(P);
+    *vals = P.vals;
+    if (ms_best) *ms_best = best;
+    return QLN_OK;
+}
+
+int qln_vals_free_placed(qln_handle* h, double* vals) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    for (size_t i = 0; i < h->placed.size(); ++i)
+        if (h->placed[i].vals == vals) {
+            (void)hipStreamSynchronize(h->stream);
+            release_placed(h->placed[i]);
+            h->placed.erase(h->placed.begin() + (long)i);
+            return QLN_OK;
+        }
+    return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_free_placed: not a buffer of this handle");
 }
 
 // ------------------------------------------------------------------ measurement

@@ -91,6 +91,24 @@ def _torch():
 JAC_FORMATS = {"dense_blocks": _lib.QLN_JAC_FORMAT_DENSE_BLOCKS, "structural": _lib.QLN_JAC_FORMAT_STRUCTURAL}
 
 
+class _PlacedBuffer:
+    """Owner of a buffer obtained from qln_vals_alloc_placed, exposed to torch through __cuda_array_interface__
+    (the tensor made from it keeps this object alive; the buffer goes back to the driver when both are gone)."""
+
+    def __init__(self, nlp, ptr: int, numel: int):
+        self._nlp, self._ptr = nlp, ptr
+        self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def __del__(self):
+        h = getattr(self._nlp, "_h", None)
+        if h and self._ptr:
+            try:
+                _lib.lib().qln_vals_free_placed(h, self._ptr)
+            except Exception:
+                pass
+            self._ptr = 0
+
+
 class HybridNLP:
     """Batch of B landing problems with a common horizon N on one GPU.
 
@@ -227,18 +245,37 @@ class HybridNLP:
     def new_vals(self):
         return _torch().zeros(self.dims.j_total, dtype=_torch().float64, device=self._dev())
 
-    def new_vals_placed(self, Z, c, trials: int = 4, launches: int = 3, spread: bool = True):
+    def new_vals_regions(self, Z, c):
+        """The Jacobian buffer placed across two 32-GiB regions of device memory (qln_vals_alloc_placed: HIP
+        virtual-memory API, the fused launch timed on windows of a j_total + 32 GiB range, the fastest window kept and
+        everything else released).  Returns (vals, ms) -- ms = launch time on the window kept.  Raises QlnError if the
+        device has not got j_total*8 + ~33 GiB free or the virtual-memory API fails."""
+        t = _torch()
+        self._check(Z, self.dims.z_total, "Z")
+        self._check(c, self.dims.c_total, "c")
+        ptr, ms = C.c_void_p(), C.c_float()
+        _lib.check(_lib.lib().qln_vals_alloc_placed(self._h, Z.data_ptr(), c.data_ptr(), C.byref(ptr), C.byref(ms)))
+        vals = t.as_tensor(_PlacedBuffer(self, ptr.value, int(self.dims.j_total)), device=self._dev())
+        return vals, float(ms.value)
+
+    def new_vals_placed(self, Z, c, trials: int = 4, launches: int = 3, spread: bool = True, regions: bool = True):
         """Setup-time placement choice for the (large, long-lived) Jacobian buffer.
 
-        Where the driver places a multi-GB allocation physically changes the sustained store bandwidth of
-        the hot kernel by up to ~20 % on MI355X (profiles/r01_placement_sensitivity.txt),
-        and an allocation keeps its placement for its lifetime.  The speed class is a property of the REGION of
-        device memory: consecutive allocations share it in runs of ~32 GiB (profiles/r01_placement_windows.txt).
-        This allocates `trials` candidate buffers, held simultaneously and -- with `spread` -- separated by
-        spacer allocations so that they sample different regions, times `launches` launches of the fused kernel
-        on each, keeps the fastest and frees everything else.  Returns (vals, [ms per trial]).
+        Where a multi-GB buffer lies physically changes the store bandwidth the hot kernel sustains by ~20 % on
+        MI355X: device memory behaves as 32-GiB regions, and the kernel's eight write fronts (the first four in the
+        first half of the buffer) run fastest when the two halves lie in different regions (DESIGN.md section 5,
+        profiles/r01_placement_windows.txt).  With `regions` the buffer is built that way (new_vals_regions).
+        If that is not possible (too little free memory), or `regions` is off, `trials` plain allocations are
+        timed instead -- held simultaneously and, with `spread`, ~32 GiB apart so that they sample different
+        regions -- and the fastest is kept.  Returns (vals, [ms]) -- one time per candidate tried.
         """
         t = _torch()
+        if regions:
+            try:
+                vals, ms = self.new_vals_regions(Z, c)
+                return vals, [ms]
+            except _lib.QlnError:
+                pass
         trials = max(1, int(trials))
         nbytes = 8 * int(self.dims.j_total)
         spacer_bytes = 0

@@ -399,3 +399,37 @@ def test_dense_host_jacobian_of_any_problem_in_a_batch_and_two_handles():
     ref2 = oracle_batch(other, nlp2, want_j=False)["c"]
     ok = ~np.isnan(ref2)
     assert rel_err(c2[ok], ref2[ok], floor=1.0) <= RTOL
+
+
+def test_region_placed_buffer_gives_the_same_values_and_is_released():
+    """qln_vals_alloc_placed: a buffer built with the HIP virtual-memory API behaves like any other device memory."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, _lib, problem_gen as PG
+
+    batch = PG.make_batch(300, 40, 14, 1, seed=5)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z = nlp.upload_Z(batch.Z)
+    c = nlp.new_c()
+    free0, _ = torch.cuda.mem_get_info()
+    vals, ms = nlp.new_vals_regions(Z, c)
+    assert vals.numel() == nlp.dims.j_total and vals.data_ptr() % (2 << 20) == 0 and ms > 0
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * nlp.dims.j_total + (600 << 20)  # everything outside the window went back to the driver
+    vals.zero_()  # (the padding between problems is never written)
+    nlp.eval_c_and_jac(Z, c, vals, write_constants=True)
+    c2, v2 = nlp.eval_c_and_jac(Z, write_constants=True)
+    torch.cuda.synchronize()
+    assert torch.equal(vals, v2) and torch.equal(c, c2)
+    ptr = vals.data_ptr()
+    del vals
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 > free1  # released when the tensor went away
+    # not a buffer of this handle (any more)
+    assert _lib.lib().qln_vals_free_placed(nlp._h, ptr) == _lib.QLN_ERR_INVALID_ARGUMENT
+    # a second one, left to qln_destroy
+    vals, _ = nlp.new_vals_regions(Z, c)
+    vals.zero_()
+    nlp.eval_c_and_jac(Z, c, vals, write_constants=True)
+    torch.cuda.synchronize()
+    assert torch.equal(vals, v2)
