@@ -12,6 +12,22 @@ mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --jac-format $FMT --steps 20 --warmup 3 --placement-trials 1 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+# 1b. the same command with the default setup (Jacobian buffer placed across two 32-GiB regions).  The setup times the
+#     same kernel on ~120 windows, so rocprofv3's --stats average mixes those with the timed launches; the per-dispatch
+#     trace of the run is therefore summarised over its LAST steps+warmup dispatches as well.
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_placed -- python3 $R/bench.py --workload $WL --jac-format $FMT --steps 20 --warmup 3 --no-cpu-baseline --no-other > $OUT/bench_under_rocprof_placed.json 2> $OUT/stats_placed.log || { tail -5 $OUT/stats_placed.log; exit 1; }
+cp $(find $OUT/stats_placed -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_placed_all_dispatches.csv
+python3 - <<PY
+import csv, glob
+rows = [r for f in glob.glob("$OUT/stats_placed/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f)) if "k_constraint_jacobian" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+last = rows[-23:]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in last]
+open("$OUT/kernel_stats_placed_timed_launches.csv", "w").write(
+    '"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs"\n"%s (last %d of %d dispatches of the run: 3 warm-up + 20 timed)",%d,%d,%.1f,%d,%d\n'
+    % (last[0]["Kernel_Name"], len(d), len(rows), len(d), sum(d), sum(d) / len(d), min(d), max(d)))
+print(open("$OUT/kernel_stats_placed_timed_launches.csv").read())
+PY
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum"; do
   i=$((i+1))
