@@ -226,7 +226,10 @@ static void release_placed(qln_handle::Placed& p) {
         (void)hipMemRelease(p.chunks[i]);
     }
     p.chunks.clear();
-    if (p.va) (void)hipMemAddressFree(p.va, p.va_size);
+    // The virtual range is deliberately NOT handed back (hipMemAddressFree): a later reservation can get the same
+    // addresses, and on ROCm 7.2 kernels were then seen writing through stale translations into the physical memory
+    // the range used to map (tests/test_gpu_parity.py::test_region_placed_buffer_...).  Address space is plentiful
+    // (a buffer's range is ~40 GiB of 128 TiB); the physical memory is what is released here.
     p.va = nullptr;
 }
 

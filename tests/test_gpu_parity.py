@@ -427,9 +427,13 @@ def test_region_placed_buffer_gives_the_same_values_and_is_released():
     assert free2 > free1  # released when the tensor went away
     # not a buffer of this handle (any more)
     assert _lib.lib().qln_vals_free_placed(nlp._h, ptr) == _lib.QLN_ERR_INVALID_ARGUMENT
-    # a second one, left to qln_destroy
-    vals, _ = nlp.new_vals_regions(Z, c)
-    vals.zero_()
-    nlp.eval_c_and_jac(Z, c, vals, write_constants=True)
-    torch.cuda.synchronize()
-    assert torch.equal(vals, v2)
+    # allocate / use / free repeatedly (a freed range's addresses must never serve a later buffer through stale
+    # translations: the library keeps its virtual ranges reserved), the last one is left to qln_destroy
+    for rep in range(3):
+        vals, _ = nlp.new_vals_regions(Z, c)
+        vals.zero_()
+        nlp.eval_c_and_jac(Z, c, vals, write_constants=True)
+        torch.cuda.synchronize()
+        assert torch.equal(vals, v2), rep
+        if rep < 2:
+            del vals
