@@ -72,6 +72,9 @@ def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks")
     vals, trial_ms = nlp.new_vals_placed(Z, c, trials=placement_trials, regions=placement_trials > 1)
     nlp.init_jacobian_constants(vals)  # constants are written once at setup
     build.last_trials = trial_ms
+    build.last_placement = ("plain allocation" if placement_trials <= 1 else
+                            "placed across two 32-GiB regions at setup (qln_vals_alloc_placed)" if len(trial_ms) == 1 else
+                            f"fastest of {len(trial_ms)} candidate allocations ~32 GiB apart")
     return batch, nlp, Z, c, vals
 
 
@@ -157,6 +160,7 @@ def main():
     batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
                                    jac_format=args.jac_format)
     placement_ms = list(build.last_trials)
+    placement_how = build.last_placement
     f, viol = nlp.new_f(), nlp.new_f()
     K, W = args.steps, args.warmup
 
@@ -234,7 +238,7 @@ def main():
         "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] (0-based; 'config {args.workload[-1]}' of BASELINE.md): {WORKLOADS[args.workload]['desc']}; "
                                "per-rank shard, constants of the Jacobian pre-written",
                    "jac_format": args.jac_format, "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride),
-                   "placement_trials_ms": placement_ms},
+                   "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms},
     }
     if rank == 0:
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

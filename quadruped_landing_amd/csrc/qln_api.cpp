@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -635,86 +636,129 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
     size_t gran = 0;
     QLN_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     const size_t chunk = round_up((int64_t)256 << 20, (int64_t)gran);   // physical chunks; 2 GiB and more fault on ROCm 7.2
-    const size_t region = (size_t)32 << 30;                              // period of the speed classes
-    const size_t need = (size_t)round_up(h->dims.j_total * 8, (int64_t)chunk);
+    const size_t bytes = (size_t)h->dims.j_total * 8;
+    const size_t need = (bytes + chunk - 1) / chunk;                     // chunks under vals
+    const size_t region = ((size_t)32 << 30) / chunk;                    // period of the speed classes, in chunks
+    const bool small = bytes < ((size_t)1 << 30);                        // nothing to gain: one plain mapping
     size_t free_b = 0, total_b = 0;
     QLN_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t span = need + region + chunk;
-    if (span > free_b / 10 * 9) span = free_b / 10 * 9 / chunk * chunk;
-    if (span < need + chunk) return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: not enough free device memory");
-    const size_t nchunks = span / chunk;
+    const size_t budget = free_b / 10 * 9 / chunk;                       // chunks this call may hold at once
+    if (budget < need + 1) return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: not enough free device memory");
 
-    qln_handle::Placed P;
-    P.chunk = chunk;
-    P.va_size = nchunks * chunk;
-    void* va = nullptr;
-    QLN_HIP(hipMemAddressReserve(&va, P.va_size, 0, nullptr, 0));
-    P.va = static_cast<char*>(va);
-    auto bail = [&](const std::string& what, hipError_t e) {
-        release_placed(P);
-        return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: " + what + ": " + hipGetErrorString(e));
+    // Physical memory: a slab of consecutive 256-MiB allocations (consecutive allocations are consecutive in device
+    // memory as far as the launch times can tell), long enough for the layouts tried below.
+    size_t nslab = small ? need : std::min(budget, need + region + 1);
+    std::vector<hipMemGenericAllocationHandle_t> slab;
+    auto drop_slab = [&](const std::vector<char>& keep) {
+        for (size_t i = 0; i < slab.size(); ++i)
+            if (keep.empty() || !keep[i]) (void)hipMemRelease(slab[i]);
     };
-    for (size_t i = 0; i < nchunks; ++i) {
+    for (size_t i = 0; i < nslab; ++i) {
         hipMemGenericAllocationHandle_t hd;
-        hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
-        if (e != hipSuccess) return bail("hipMemCreate", e);
-        e = hipMemMap(P.va + i * chunk, chunk, 0, hd, 0);
+        const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
         if (e != hipSuccess) {
-            (void)hipMemRelease(hd);
-            return bail("hipMemMap", e);
+            if (slab.size() >= need + 1) break;  // less than planned, still usable
+            drop_slab({});
+            return fail(QLN_ERR_HIP, std::string("qln_vals_alloc_placed: hipMemCreate: ") + hipGetErrorString(e));
         }
-        P.chunks.push_back(hd);
+        slab.push_back(hd);
     }
+    nslab = slab.size();
     hipMemAccessDesc ad = {};
     ad.location = prop.location;
     ad.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipError_t e = hipMemSetAccess(P.va, P.va_size, &ad, 1); e != hipSuccess) return bail("hipMemSetAccess", e);
 
-    // coarse scan (1-GiB steps), then 256-MiB steps around the best window
-    const size_t last = P.va_size - need;
-    size_t best_off = 0;
-    float best = 1e30f;
-    auto probe = [&](size_t off) {
-        float ms = 0.f;
-        const int rc = time_fused(h, Z, c, reinterpret_cast<double*>(P.va + off), 1, 2, &ms);
-        if (rc == QLN_OK && ms < best) {
-            best = ms;
-            best_off = off;
-        }
-        return rc;
+    // a virtual range with slab chunk pick[j] behind its j-th chunk
+    struct View {
+        char* va = nullptr;
+        size_t n = 0;
     };
-    const size_t coarse = (size_t)1 << 30;
-    for (size_t off = 0; off <= last; off += coarse)
-        if (int rc = probe(off)) {
-            release_placed(P);
+    auto map_view = [&](View& v, const std::vector<size_t>& pick) -> hipError_t {
+        if (!v.va) {
+            void* p = nullptr;
+            if (hipError_t e = hipMemAddressReserve(&p, pick.size() * chunk, 0, nullptr, 0); e != hipSuccess) return e;
+            v.va = static_cast<char*>(p);
+        }
+        v.n = pick.size();
+        for (size_t j = 0; j < pick.size(); ++j)
+            if (hipError_t e = hipMemMap(v.va + j * chunk, chunk, 0, slab[pick[j]], 0); e != hipSuccess) return e;
+        return hipMemSetAccess(v.va, v.n * chunk, &ad, 1);
+    };
+    auto unmap_view = [&](View& v) {
+        if (v.va && v.n) (void)hipMemUnmap(v.va, v.n * chunk);
+        v.n = 0;
+    };
+    auto fail_hip = [&](const char* what, hipError_t e) {
+        drop_slab({});
+        return fail(QLN_ERR_HIP, std::string("qln_vals_alloc_placed: ") + what + ": " + hipGetErrorString(e));
+    };
+
+    std::vector<size_t> final_pick;
+    View final_view;
+    size_t final_off = 0;  // chunks
+    float best = 0.f;
+    if (small) {
+        final_pick.resize(need);
+        for (size_t j = 0; j < need; ++j) final_pick[j] = j;
+        if (hipError_t e = map_view(final_view, final_pick); e != hipSuccess) return fail_hip("map", e);
+        if (int rc = time_fused(h, Z, c, reinterpret_cast<double*>(final_view.va), 1, 2, &best)) {
+            drop_slab({});
             return rc;
         }
-    {
-        const size_t centre = best_off;
-        for (int k = -3; k <= 3; ++k) {
-            if (k == 0) continue;
-            const int64_t off = (int64_t)centre + (int64_t)k * (int64_t)chunk;
-            if (off < 0 || (size_t)off > last) continue;
-            if (int rc = probe((size_t)off)) {
-                release_placed(P);
-                return rc;
+    } else {
+        // The slab as it lies, the fused launch timed on its windows: the best one straddles a region boundary (XCDs
+        // 0-3 write one region, XCDs 4-7 the next).  Giving every XCD's range a region of its own (ranges 16 GiB
+        // apart) was tried as a second layout: 1.10 ms against 1.08-1.10 ms for the best window, so it is not built.
+        View lin;
+        const size_t nlin = std::min(nslab, need + region + 1);
+        std::vector<size_t> pick(nlin);
+        for (size_t j = 0; j < nlin; ++j) pick[j] = j;
+        if (hipError_t e = map_view(lin, pick); e != hipSuccess) return fail_hip("map", e);
+        size_t best_off = 0;
+        float t_lin = 1e30f;
+        auto probe = [&](size_t off) {
+            float ms = 0.f;
+            const int rc = time_fused(h, Z, c, reinterpret_cast<double*>(lin.va + off * chunk), 1, 2, &ms);
+            if (rc == QLN_OK && ms < t_lin) {
+                t_lin = ms;
+                best_off = off;
             }
+            return rc;
+        };
+        int rc = QLN_OK;
+        for (size_t off = 0; off + need <= nlin && rc == QLN_OK; off += 4) rc = probe(off);  // 1-GiB steps
+        const size_t centre = best_off;
+        for (int k = -3; k <= 3 && rc == QLN_OK; ++k) {
+            const int64_t off = (int64_t)centre + k;
+            if (k != 0 && off >= 0 && (size_t)off + need <= nlin) rc = probe((size_t)off);
         }
-    }
-    // keep the chunks under the window, give the rest back
-    const size_t c0 = best_off / chunk, c1 = (best_off + need) / chunk;  // [c0, c1)
-    std::vector<hipMemGenericAllocationHandle_t> keep;
-    for (size_t i = 0; i < P.chunks.size(); ++i) {
-        if (i >= c0 && i < c1) {
-            keep.push_back(P.chunks[i]);
-        } else {
-            (void)hipMemUnmap(P.va + i * chunk, chunk);
-            (void)hipMemRelease(P.chunks[i]);
+        if (rc != QLN_OK) {
+            unmap_view(lin);
+            drop_slab({});
+            return rc;
         }
+        // everything outside the window is unmapped; the window keeps its addresses
+        final_pick.resize(need);
+        for (size_t j = 0; j < need; ++j) final_pick[j] = best_off + j;
+        for (size_t j = 0; j < nlin; ++j)
+            if (j < best_off || j >= best_off + need) (void)hipMemUnmap(lin.va + j * chunk, chunk);
+        if (getenv("QLN_PLACEMENT_VERBOSE"))
+            fprintf(stderr, "qln_vals_alloc_placed: %zu chunks of %zu MiB scanned; best window at chunk %zu: %.3f ms\n", nlin,
+                    chunk >> 20, best_off, t_lin);
+        final_view = lin;
+        final_off = best_off;
+        best = t_lin;
     }
-    P.chunks.swap(keep);
-    P.first = c0;
-    P.vals = reinterpret_cast<double*>(P.va + best_off);
+    // give back every chunk that is not under the buffer
+    std::vector<char> keep(nslab, 0);
+    for (size_t j : final_pick) keep[j] = 1;
+    drop_slab(keep);
+    qln_handle::Placed P;
+    P.chunk = chunk;
+    P.va = final_view.va;
+    P.first = final_off;
+    for (size_t j : final_pick) P.chunks.push_back(slab[j]);
+    P.vals = reinterpret_cast<double*>(final_view.va + final_off * chunk);
     h->placed.push_back(P);
     *vals = P.vals;
     if (ms_best) *ms_best = best;
