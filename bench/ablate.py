@@ -16,7 +16,8 @@ def t_ms(fn, iters=20):
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "config3"
 fmt = sys.argv[2] if len(sys.argv) > 2 else "dense_blocks"
-batch, nlp, Z, c, vals = build(wl, 0, 0, jac_format=fmt)
+# QLN_ABLATE_PLACED=1: the Jacobian buffer placed across two 32-GiB regions (as bench.py does), else a plain allocation
+batch, nlp, Z, c, vals = build(wl, 0, 0, placement_trials=8 if os.environ.get("QLN_ABLATE_PLACED") else 1, jac_format=fmt)
 f = nlp.new_f(); g = nlp.new_Z()
 print(wl, "fused c+J      : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=False)))
 print(wl, "fused +consts  : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=True)))
