@@ -237,6 +237,7 @@ static void release_placed(qln_handle::Placed& p) {
 int qln_destroy(qln_handle* h) {
     if (!h) return QLN_OK;
     (void)hipSetDevice(h->device);
+    if (!h->placed.empty()) (void)hipStreamSynchronize(h->stream);  // nothing may still be writing to memory about to be unmapped
     for (auto& p : h->placed) release_placed(p);
     void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
     for (void* b : bufs)
