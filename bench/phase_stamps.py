@@ -11,7 +11,7 @@ from bench import build
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "config3"
 fmt = sys.argv[2] if len(sys.argv) > 2 else "dense_blocks"
-batch, nlp, Z, c, vals = build(wl, 0, 0, jac_format=fmt)
+batch, nlp, Z, c, vals = build(wl, 0, 0, placement_trials=8 if os.environ.get("QLN_ABLATE_PLACED") else 1, jac_format=fmt)
 L = _lib.lib()
 stamps = torch.zeros(batch.B * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):

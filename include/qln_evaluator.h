@@ -203,11 +203,11 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
  * regions, and the evaluator's eight write fronts (one per XCD, the first four in the first half of vals) run ~20 %
  * faster when the two halves of the buffer lie in different regions (DESIGN.md section 5,
  * profiles/r01_placement_windows.txt).  This call builds such a buffer with the HIP virtual-memory API: it maps
- * j_total doubles + 32 GiB of physical memory in 256-MiB chunks behind one virtual range, times the fused launch
+ * j_total doubles + 64 GiB of physical memory in 256-MiB chunks behind one virtual range, times the fused launch
  * (Z, c as for qln_eval_constraint_and_jacobian; c is overwritten) on windows of that range, keeps the fastest window
  * and returns every chunk outside it to the driver.  *vals is at least 2-MiB aligned and holds j_total doubles; constants are
- * not written.  ms_best (may be NULL): launch time on the window kept.  Needs j_total*8 + ~33 GiB of free device
- * memory for the duration of the call; QLN_ERR_HIP if that (or the virtual-memory API) is not available.
+ * not written.  ms_best (may be NULL): launch time on the window kept.  Uses up to j_total*8 + ~65 GiB of free device
+ * memory for the duration of the call (less if less is free); QLN_ERR_HIP if that (or the virtual-memory API) is not available.
  * Release with qln_vals_free_placed (qln_destroy releases what is left). */
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best);
 int qln_vals_free_placed(qln_handle* h, double* vals);

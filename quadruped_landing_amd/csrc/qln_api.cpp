@@ -648,7 +648,8 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
 
     // Physical memory: a slab of consecutive 256-MiB allocations (consecutive allocations are consecutive in device
     // memory as far as the launch times can tell), long enough for the layouts tried below.
-    size_t nslab = small ? need : std::min(budget, need + region + 1);
+    // two region lengths: the slab then contains two boundaries, i.e. two chances of a clean straddling window
+    size_t nslab = small ? need : std::min(budget, need + 2 * region + 1);
     std::vector<hipMemGenericAllocationHandle_t> slab;
     auto drop_slab = [&](const std::vector<char>& keep) {
         for (size_t i = 0; i < slab.size(); ++i)
@@ -711,7 +712,7 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
         // 0-3 write one region, XCDs 4-7 the next).  Giving every XCD's range a region of its own (ranges 16 GiB
         // apart) was tried as a second layout: 1.10 ms against 1.08-1.10 ms for the best window, so it is not built.
         View lin;
-        const size_t nlin = std::min(nslab, need + region + 1);
+        const size_t nlin = nslab;
         std::vector<size_t> pick(nlin);
         for (size_t j = 0; j < nlin; ++j) pick[j] = j;
         if (hipError_t e = map_view(lin, pick); e != hipSuccess) return fail_hip("map", e);

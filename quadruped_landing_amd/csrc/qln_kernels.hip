@@ -116,17 +116,21 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS address
 }
 
-// The block stream is written once and not read again by this launch: non-temporal stores (-1.4 % on a region-placed
-// buffer, profiles/r01_nt_stores.txt).
-__device__ __forceinline__ void stream_store(double2* dst, v2f64 v) {
-    __builtin_nontemporal_store(v, reinterpret_cast<v2f64*>(dst));
+// The block stream is written once and not read again by this launch: non-temporal stores when the output is larger
+// than the caches (-1.5 % on a region-placed buffer, profiles/r01_nt_stores.txt); for small batches, whose output
+// stays in L2 / the Infinity Cache, plain stores are the faster ones (B = 1024: 24 against 29 us).
+template <bool STREAM>
+__device__ __forceinline__ void block_store(double2* dst, v2f64 v) {
+    if constexpr (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<v2f64*>(dst));
+    else *reinterpret_cast<v2f64*>(dst) = v;
 }
-__device__ __forceinline__ void stream_store(double2* dst, double2 v) {
+template <bool STREAM>
+__device__ __forceinline__ void block_store(double2* dst, double2 v) {
     v2f64 t = {v.x, v.y};
-    stream_store(dst, t);
+    block_store<STREAM>(dst, t);
 }
 
-template <int STEP>
+template <int STEP, bool STREAM>
 __device__ __forceinline__ void drain6(uint32_t lds, double2* dst) {
     v2f64 r0, r1, r2, r3, r4, r5;
     asm volatile(
@@ -140,29 +144,30 @@ __device__ __forceinline__ void drain6(uint32_t lds, double2* dst) {
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
         : "v"(lds)
         : "memory");
-    stream_store(dst + 0 * STEP, r0);
-    stream_store(dst + 1 * STEP, r1);
-    stream_store(dst + 2 * STEP, r2);
-    stream_store(dst + 3 * STEP, r3);
-    stream_store(dst + 4 * STEP, r4);
-    stream_store(dst + 5 * STEP, r5);
+    block_store<STREAM>(dst + 0 * STEP, r0);
+    block_store<STREAM>(dst + 1 * STEP, r1);
+    block_store<STREAM>(dst + 2 * STEP, r2);
+    block_store<STREAM>(dst + 3 * STEP, r3);
+    block_store<STREAM>(dst + 4 * STEP, r4);
+    block_store<STREAM>(dst + 5 * STEP, r5);
 }
 
+template <bool STREAM>
 __device__ __forceinline__ void drain1(uint32_t lds, double2* dst) {
     v2f64 r0;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(lds) : "memory");
-    stream_store(dst, r0);
+    block_store<STREAM>(dst, r0);
 }
 
 // REM full pieces starting at (lds, dst), both already offset by the lane
-template <int REM, int STEP>
+template <int REM, int STEP, bool STREAM>
 __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
     if constexpr (REM >= 6) {
-        drain6<STEP>(lds, dst);
-        drain_full<REM - 6, STEP>(lds + 6 * 1024, dst + 6 * STEP);
+        drain6<STEP, STREAM>(lds, dst);
+        drain_full<REM - 6, STEP, STREAM>(lds + 6 * 1024, dst + 6 * STEP);
     } else if constexpr (REM > 0) {
-        drain1(lds, dst);
-        drain_full<REM - 1, STEP>(lds + 1024, dst + STEP);
+        drain1<STREAM>(lds, dst);
+        drain_full<REM - 1, STEP, STREAM>(lds + 1024, dst + STEP);
     }
 }
 
@@ -176,7 +181,8 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 // NNZ = structural format (QLN_JAC_FORMAT_STRUCTURAL): T is unused, the tile holds the chunk's KC compact blocks
 // SPLIT = small batches: one workgroup per CHUNK of KC knots instead of per problem, so that a batch with fewer
 //         problems than the chip has SIMDs still fills it (the launch is then as long as one chunk, not one problem)
-template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false, bool SPLIT = false>
+// STREAM = non-temporal stores for the outputs (large batches)
+template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false, bool SPLIT = false, bool STREAM = true>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
                                                               double* __restrict__ V, uint32_t flags) {
@@ -374,7 +380,10 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
 #pragma unroll
                 for (int it = 0; it < kCIters; ++it) {
                     const int i = it * kWave + lane;
-                    if (i < np) __builtin_nontemporal_store(cr[it], &dst[i]);  // streamed like the blocks (-1 %)
+                    if (i < np) {
+                        if constexpr (STREAM) __builtin_nontemporal_store(cr[it], &dst[i]);  // streamed like the blocks (-1 %)
+                        else dst[i] = cr[it];
+                    }
                 }
             }
         }
@@ -477,9 +486,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                     const double2* src = s_j2 + p0 + lane;
                     int it = 0;
 #pragma unroll 1
-                    for (; (it + 6) * kWave <= np; it += 6) drain6<kWave>(lds_offset(src + it * kWave), dst + it * kWave);
+                    for (; (it + 6) * kWave <= np; it += 6) drain6<kWave, STREAM>(lds_offset(src + it * kWave), dst + it * kWave);
 #pragma unroll 1
-                    for (; it * kWave + lane < np; ++it) stream_store(dst + it * kWave, src[it * kWave]);
+                    for (; it * kWave + lane < np; ++it) block_store<STREAM>(dst + it * kWave, src[it * kWave]);
                 }
                 wave_lds_sync();
                 QLN_STAMP(5);
@@ -507,17 +516,17 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                     constexpr int kPieces = T * kBlk / 2;   // 16-byte pieces in a full tile
                     constexpr int kFull = kPieces / kWave;  // unpredicated wave instructions
                     if (nkt == T) {
-                        drain_full<kFull, kStep>(lds_offset(s_j2 + lane), dst);
+                        drain_full<kFull, kStep, STREAM>(lds_offset(s_j2 + lane), dst);
                         if (kPieces % kWave) {
-                            if (kFull * kWave + lane < kPieces) stream_store(dst + kFull * kStep, s_j2[kFull * kWave + lane]);
+                            if (kFull * kWave + lane < kPieces) block_store<STREAM>(dst + kFull * kStep, s_j2[kFull * kWave + lane]);
                         }
                     } else {
                         // last, partial sub-tile of a chunk: whole 6-instruction batches, then a predicated tail
                         int it = 0;
 #pragma unroll 1
-                        for (; (it + 6) * kWave <= np; it += 6) drain6<kStep>(lds_offset(s_j2 + it * kWave + lane), dst + (int64_t)it * kStep);
+                        for (; (it + 6) * kWave <= np; it += 6) drain6<kStep, STREAM>(lds_offset(s_j2 + it * kWave + lane), dst + (int64_t)it * kStep);
 #pragma unroll 1
-                        for (; it * kWave + lane < np; ++it) stream_store(dst + (int64_t)it * kStep, s_j2[it * kWave + lane]);
+                        for (; it * kWave + lane < np; ++it) block_store<STREAM>(dst + (int64_t)it * kStep, s_j2[it * kWave + lane]);
                     }
                 }
                 wave_lds_sync();
@@ -812,12 +821,18 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
 #else
     constexpr unsigned pad = 0;
 #endif
-    if (c && vals)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, true, NNZ, SPLIT>), grid, block, pad, stream, p, b_begin, nb, Z, c, vals, flags);
-    else if (c)
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, NNZ, SPLIT>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
-    else
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, false, true, NNZ, SPLIT>), grid, block, 0, stream, p, b_begin, nb, Z, c, vals, flags);
+    // outputs larger than the caches are streamed (non-temporal stores); small ones stay cacheable
+    const bool stream_out = (int64_t)nb * (p.N - 1) * (NNZ ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
+    auto go = [&](auto with_c, auto with_j, auto streamed) {
+        constexpr bool WC = decltype(with_c)::value, WJ = decltype(with_j)::value, ST = decltype(streamed)::value;
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, WC, WJ, NNZ, SPLIT, ST>), grid, block, (WC && WJ) ? pad : 0u, stream, p,
+                           b_begin, nb, Z, c, vals, flags);
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    if (c && vals) stream_out ? go(yes{}, yes{}, yes{}) : go(yes{}, yes{}, no{});
+    else if (c) stream_out ? go(yes{}, no{}, yes{}) : go(yes{}, no{}, no{});
+    else stream_out ? go(no{}, yes{}, yes{}) : go(no{}, yes{}, no{});
     return hipGetLastError();
 }
 
