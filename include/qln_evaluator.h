@@ -199,16 +199,17 @@ int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* va
 int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const double* Z, double* jac);
 
 /* Placement-aware allocation of the Jacobian buffer (optional; every entry point also accepts plain hipMalloc memory).
- * On MI355X the store bandwidth a buffer sustains depends on where it lies physically: device memory behaves as 32-GiB
- * regions, and the evaluator's eight write fronts (one per XCD, the first four in the first half of vals) run ~20 %
- * faster when the two halves of the buffer lie in different regions (DESIGN.md section 5,
- * profiles/r01_placement_windows.txt).  This call builds such a buffer with the HIP virtual-memory API: it maps
- * j_total doubles + 64 GiB of physical memory in 256-MiB chunks behind one virtual range, times the fused launch
- * (Z, c as for qln_eval_constraint_and_jacobian; c is overwritten) on windows of that range, keeps the fastest window
- * and returns every chunk outside it to the driver.  *vals is at least 2-MiB aligned and holds j_total doubles; constants are
- * not written.  ms_best (may be NULL): launch time on the window kept.  Uses up to j_total*8 + ~65 GiB of free device
- * memory for the duration of the call (less if less is free); QLN_ERR_HIP if that (or the virtual-memory API) is not available.
- * Release with qln_vals_free_placed (qln_destroy releases what is left). */
+ * On MI355X the store bandwidth a buffer sustains depends on where it lies physically: device memory behaves as
+ * 32-GiB regions, and the evaluator's eight write fronts (one per XCD, the first four in the first half of vals) run
+ * ~20 % faster when the two halves of the buffer lie in different regions (DESIGN.md section 5,
+ * profiles/r01_placement_regions.txt).  This call builds such a buffer with the HIP virtual-memory API: it maps
+ * j_total doubles + 64 GiB of physical memory (less if less is free) in 256-MiB chunks behind one virtual range,
+ * times the fused launch on windows of that range (Z, c as for qln_eval_constraint_and_jacobian; c is overwritten),
+ * keeps the fastest window and returns every chunk outside it to the driver.  Buffers under 1 GiB are mapped as they
+ * come.  *vals is at least 2-MiB aligned and holds j_total doubles; constants are not written.  ms_best (may be NULL):
+ * launch time on the window kept.  QLN_ERR_HIP if the memory or the virtual-memory API is not available.  Release with
+ * qln_vals_free_placed (qln_destroy releases what is left); the virtual range itself stays reserved for the life of
+ * the process (its addresses are never reused). */
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best);
 int qln_vals_free_placed(qln_handle* h, double* vals);
 
