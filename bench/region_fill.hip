@@ -19,6 +19,18 @@ __global__ __launch_bounds__(64) void k_fill(char* slab, Offs offs, int per_xcd,
     for (int j = threadIdx.x; j < region2; j += 64) q[j] = v;
 }
 
+// the same shape, reading instead of writing (does a consumer of the Jacobian see the regions too?)
+__global__ __launch_bounds__(64) void k_read(const char* slab, Offs offs, int per_xcd, int region2, size_t stride2, double* sink) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const double2* q = reinterpret_cast<const double2*>(slab + offs.o[x]) + (size_t)i * stride2;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < region2; j += 64) {
+        const double2 v = q[j];
+        acc += v.x + v.y;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;  // never true; keeps the loads
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const double gib = argc > 1 ? atof(argv[1]) : 192;
@@ -30,11 +42,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&slab, slab_bytes));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const bool reading = getenv("READ") != nullptr;
+    double* sink;
+    CK(hipMalloc(&sink, 8));
+    if (reading) { CK(hipMemset(slab, 0, slab_bytes)); printf("READ mode\n"); }
     auto run = [&](const Offs& o) {
         std::vector<float> t;
         for (int r = 0; r < 6; ++r) {
             CK(hipEventRecord(e0));
-            k_fill<<<B, 64>>>(slab, o, per_xcd, (int)(region / 2), stride / 2);
+            if (reading) k_read<<<B, 64>>>(slab, o, per_xcd, (int)(region / 2), stride / 2, sink);
+            else k_fill<<<B, 64>>>(slab, o, per_xcd, (int)(region / 2), stride / 2);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 2) t.push_back(ms);
