@@ -245,3 +245,39 @@ def test_problems_too_large_for_lds_are_refused():
     dZ = nlp.gauss_newton_step(Z, c, max_iters=3, rel_tol=0.0)
     torch.cuda.synchronize()
     assert torch.isfinite(dZ.view(2, -1)[:, : nlp.n_nlp]).all()
+
+
+def test_gauss_newton_random_shapes_property():
+    """Randomised shapes (hypothesis): both code paths of the step kernel (step blocks cached in registers for N <= 64,
+    re-derived for larger N), ragged k_trans / init_mode, strides and alignments, with and without scaling / radius."""
+    import scipy.sparse as sp
+    import torch
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    @settings(max_examples=12, deadline=None)
+    @given(B=st.integers(1, 6), N=st.integers(2, 100), pad=st.integers(0, 5), align=st.sampled_from([1, 2, 16]),
+           scaled=st.booleans(), seed=st.integers(0, 10**6))
+    def check(B, N, pad, align, scaled, seed):
+        batch = PG.make_batch(B, N, seed=seed, ragged=True) if N > 3 else PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                        z_stride=(20 * N - 5 + pad) if pad else 0, align=align)
+        Z = nlp.upload_Z(batch.Z)
+        c = nlp.eval_c(Z)
+        ref = oracle_batch(batch, nlp)
+        rng = np.random.default_rng(seed)
+        d = rng.uniform(0.5, 2.0, size=nlp.n_nlp) if scaled else np.ones(nlp.n_nlp)
+        if scaled:
+            d[rng.integers(0, nlp.n_nlp, size=3)] = 0.0
+        systems = [_system(batch, nlp, ref, b) for b in range(B)]
+        radii = [0.7 * np.linalg.norm(_cgls(A @ sp.diags(d), rho, 2)[0]) if scaled else 1e30 for A, rho in systems]
+        dZ = nlp.gauss_newton_step(Z, c, max_iters=2, rel_tol=0.0,
+                                   radius=torch.tensor(radii, dtype=torch.float64, device="cuda") if scaled else None,
+                                   col_scale=torch.from_numpy(d).cuda() if scaled else None)
+        torch.cuda.synchronize()
+        dZ = dZ.cpu().numpy().reshape(B, -1)
+        for b, (A, rho) in enumerate(systems):
+            x, *_ = _steihaug_cgls(A @ sp.diags(d), rho, radii[b], 2)
+            assert np.abs(dZ[b, : nlp.n_nlp] - d * x).max() <= 1e-8 * np.abs(d * x).max(), (B, N, b)
+
+    check()
