@@ -19,6 +19,12 @@ __global__ __launch_bounds__(64) void k_fill(char* slab, Offs offs, int per_xcd,
     for (int j = threadIdx.x; j < region2; j += 64) q[j] = v;
 }
 
+// flat grid-stride fill of one contiguous range (what hipMemset-like code does): the ceiling of any layout
+__global__ void k_flat(double2* p, size_t n2) {
+    const double2 v = make_double2(1.0, 2.0);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // the same shape, reading instead of writing (does a consumer of the Jacobian see the regions too?)
 __global__ __launch_bounds__(64) void k_read(const char* slab, Offs offs, int per_xcd, int region2, size_t stride2, double* sink) {
     const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -105,6 +111,21 @@ int main(int argc, char** argv) {
             for (int x = 0; x < 8; ++x) o.o[x] = (long long)(((x & 3) * D) * (1ull << 30)) + (long long)(x >> 2) * range_bytes;
             float ms = run(o);
             printf("four groups of two, %5.1f GiB apart: %.3f ms  %.0f GB/s\n", D, ms, wbytes / ms / 1e6);
+        }
+    }
+    if (getenv("FLAT")) {
+        // flat fill of 6.29 GiB starting at offset s: inside one region, and across a boundary
+        for (double sgib = 0; sgib + 6.5 <= gib && sgib <= 72; sgib += 2.0) {
+            std::vector<float> t;
+            for (int r = 0; r < 5; ++r) {
+                CK(hipEventRecord(e0));
+                k_flat<<<4096, 256>>>(reinterpret_cast<double2*>(slab + (size_t)(sgib * (1ull << 30))), (size_t)8 * range_bytes / 16);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 1) t.push_back(ms);
+            }
+            std::sort(t.begin(), t.end());
+            printf("flat fill at %5.1f GiB: %.3f ms  %.0f GB/s\n", sgib, t[t.size() / 2], 8.0 * range_bytes / t[t.size() / 2] / 1e6);
         }
     }
     // (3) all eight ranges inside the best and inside the worst 8-GiB window found in (1)
