@@ -188,7 +188,8 @@ int qln_set_lqr_cost(qln_handle* h, const double* Qdiag, const double* Rdiag, co
 /* Copies the handle's cost table ([cost_batch][N][41]) to a host buffer; cost_batch is returned through *cost_batch. */
 int qln_get_cost(qln_handle* h, double* cost_host, int32_t* cost_batch);
 
-/* MOI mode: HOST pointers, synchronous (H2D, launch, D2H inside).  Same layouts. */
+/* MOI mode: HOST pointers, synchronous.  Same layouts.  Batches of up to 8 MB per callback are evaluated on mapped
+ * pinned host memory directly (one launch, no copies); larger ones are staged through device memory. */
 int qln_eval_objective_host(qln_handle* h, const double* Z, double* f);
 int qln_eval_objective_gradient_host(qln_handle* h, const double* Z, double* grad);
 int qln_eval_constraint_host(qln_handle* h, const double* Z, double* c);

@@ -73,6 +73,14 @@ struct qln_handle {
     double* s_f = nullptr;
     double* s_grad = nullptr;
     std::vector<double> h_vals_one;
+    // zero-copy MOI mode (small batches): pinned host buffers mapped into the device's address space -- the kernels read
+    // Z from and write their results to host memory directly, so a callback is one launch and one synchronisation
+    struct Mapped {
+        double* host = nullptr;
+        double* dev = nullptr;
+    };
+    Mapped m_Z, m_c, m_vals, m_f, m_grad;
+    bool zero_copy = false;
     // buffers handed out by qln_vals_alloc_placed
     struct Placed {
         char* va = nullptr;        // reserved virtual range
@@ -97,6 +105,21 @@ int upload(T** dst, const T* src, size_t n) {
 int ensure(double** buf, int64_t n) {
     if (*buf) return QLN_OK;
     QLN_HIP(hipMalloc(reinterpret_cast<void**>(buf), std::max<int64_t>(n, 1) * sizeof(double)));
+    return QLN_OK;
+}
+
+int ensure_mapped(qln_handle::Mapped* m, int64_t n) {
+    if (m->host) return QLN_OK;
+    void* hp = nullptr;
+    QLN_HIP(hipHostMalloc(&hp, std::max<int64_t>(n, 1) * sizeof(double), hipHostMallocMapped));
+    std::memset(hp, 0, std::max<int64_t>(n, 1) * sizeof(double));  // padding the kernels never write stays zero
+    void* dp = nullptr;
+    if (hipError_t e = hipHostGetDevicePointer(&dp, hp, 0); e != hipSuccess) {
+        (void)hipHostFree(hp);
+        return fail(QLN_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    m->host = static_cast<double*>(hp);
+    m->dev = static_cast<double*>(dp);
     return QLN_OK;
 }
 
@@ -217,6 +240,10 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     P.cost_batch = d->cost_batch;
     P.z_stride = z_stride;
     P.jac_format = fmt;
+    // host-pointer (MOI) mode: up to 8 MB per callback the kernels work on mapped host memory directly (one launch, no
+    // copies: 19-21 us against 32 us for the notebook's problem, profiles/r01_moi_latency.txt); larger batches are
+    // staged through device memory
+    h->zero_copy = (D.z_total + D.c_total + D.j_total) * (int64_t)sizeof(double) <= ((int64_t)8 << 20);
     *out = h;
     return QLN_OK;
 }
@@ -239,6 +266,8 @@ int qln_destroy(qln_handle* h) {
     (void)hipSetDevice(h->device);
     if (!h->placed.empty()) (void)hipStreamSynchronize(h->stream);  // nothing may still be writing to memory about to be unmapped
     for (auto& p : h->placed) release_placed(p);
+    for (qln_handle::Mapped* m : {&h->m_Z, &h->m_c, &h->m_vals, &h->m_f, &h->m_grad})
+        if (m->host) (void)hipHostFree(m->host);
     void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -512,6 +541,15 @@ int qln_eval_objective_host(qln_handle* h, const double* Z, double* f) {
     if (int rc = check_cost(h)) return rc;
     if (!Z || !f) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_host: null pointer");
     if (int rc = bind_device(h)) return rc;
+    if (h->zero_copy) {
+        if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure_mapped(&h->m_f, h->dims.B)) return rc;
+        std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
+        QLN_HIP(qln::launch_objective(h->p, h->m_Z.dev, h->m_f.dev, h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(f, h->m_f.host, h->dims.B * sizeof(double));
+        return QLN_OK;
+    }
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
     if (int rc = ensure(&h->s_f, h->dims.B)) return rc;
     QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -526,6 +564,15 @@ int qln_eval_objective_gradient_host(qln_handle* h, const double* Z, double* gra
     if (int rc = check_cost(h)) return rc;
     if (!Z || !grad) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_gradient_host: null pointer");
     if (int rc = bind_device(h)) return rc;
+    if (h->zero_copy) {
+        if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure_mapped(&h->m_grad, h->dims.z_total)) return rc;
+        std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
+        QLN_HIP(qln::launch_objective_gradient(h->p, h->m_Z.dev, h->m_grad.dev, h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(grad, h->m_grad.host, h->dims.z_total * sizeof(double));
+        return QLN_OK;
+    }
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
     if (int rc = ensure(&h->s_grad, h->dims.z_total)) return rc;
     QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -540,6 +587,15 @@ int qln_eval_constraint_host(qln_handle* h, const double* Z, double* c) {
     if (int rc = check_handle(h)) return rc;
     if (!Z || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_host: null pointer");
     if (int rc = bind_device(h)) return rc;
+    if (h->zero_copy) {
+        if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure_mapped(&h->m_c, h->dims.c_total)) return rc;
+        std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, h->m_c.dev, nullptr, 0, h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(c, h->m_c.host, h->dims.c_total * sizeof(double));
+        return QLN_OK;
+    }
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
     if (int rc = ensure(&h->s_c, h->dims.c_total)) return rc;
     QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -553,6 +609,16 @@ int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* va
     if (int rc = check_handle(h)) return rc;
     if (!Z || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian_host: null pointer");
     if (int rc = bind_device(h)) return rc;
+    if (h->zero_copy) {
+        if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure_mapped(&h->m_vals, h->dims.j_total)) return rc;
+        std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, nullptr, h->m_vals.dev, QLN_JAC_WRITE_CONSTANTS,
+                                                h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(vals, h->m_vals.host, h->dims.j_total * sizeof(double));
+        return QLN_OK;
+    }
     if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
     if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
     QLN_HIP(hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -570,18 +636,29 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
     if (int rc = check_problem(h, b)) return rc;
     if (!Z || !jac) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian_dense_host: null pointer");
     if (int rc = bind_device(h)) return rc;
-    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
-    if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
     const int32_t N = h->dims.N, kt = h->k_trans[b];
     const int32_t nnz = nnz_of(N, kt, h->p.jac_format);
     const int64_t m = m_nlp_of(N, kt);
-    h->h_vals_one.resize(nnz);
-    QLN_HIP(hipMemcpyAsync(h->s_Z + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double), hipMemcpyHostToDevice,
-                           h->stream));
-    QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->s_Z, nullptr, h->s_vals, QLN_JAC_WRITE_CONSTANTS, h->stream));
-    QLN_HIP(hipMemcpyAsync(h->h_vals_one.data(), h->s_vals + h->j_off[b], nnz * sizeof(double), hipMemcpyDeviceToHost,
-                           h->stream));
-    QLN_HIP(hipStreamSynchronize(h->stream));
+    const double* v = nullptr;
+    if (h->zero_copy) {
+        if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure_mapped(&h->m_vals, h->dims.j_total)) return rc;
+        std::memcpy(h->m_Z.host + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->m_Z.dev, nullptr, h->m_vals.dev, QLN_JAC_WRITE_CONSTANTS, h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        v = h->m_vals.host + h->j_off[b];
+    } else {
+        if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+        if (int rc = ensure(&h->s_vals, h->dims.j_total)) return rc;
+        h->h_vals_one.resize(nnz);
+        QLN_HIP(hipMemcpyAsync(h->s_Z + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double), hipMemcpyHostToDevice,
+                               h->stream));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->s_Z, nullptr, h->s_vals, QLN_JAC_WRITE_CONSTANTS, h->stream));
+        QLN_HIP(hipMemcpyAsync(h->h_vals_one.data(), h->s_vals + h->j_off[b], nnz * sizeof(double), hipMemcpyDeviceToHost,
+                               h->stream));
+        QLN_HIP(hipStreamSynchronize(h->stream));
+        v = h->h_vals_one.data();
+    }
     std::vector<int32_t> rows(nnz), cols(nnz);
     if (int rc = qln_jacobian_structure(h, b, rows.data(), cols.data())) return rc;
     // D[ci, xi[k+1]] .= -I(n) assigns the whole 15x15 block (explicit zeros off the diagonal)
@@ -596,7 +673,6 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
         for (int32_t k = 0; k < N - 1; ++k)
             for (int32_t c = 0; c < 20; ++c)
                 for (int32_t r = 0; r < 15; ++r) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * k + c)] = 0.0;
-    const double* v = h->h_vals_one.data();
     for (int32_t e = 0; e < nnz; ++e) jac[rows[e] + m * (int64_t)cols[e]] = v[e];
     return QLN_OK;
 }

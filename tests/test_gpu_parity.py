@@ -437,3 +437,33 @@ def test_region_placed_buffer_gives_the_same_values_and_is_released():
         assert torch.equal(vals, v2), rep
         if rep < 2:
             del vals
+
+
+@pytest.mark.parametrize("B", [5, 160])
+def test_host_pointer_mode_both_paths(B):
+    """MOI-mode entry points on host buffers: small batches work on mapped host memory directly (zero copy), batches
+    above 8 MB per callback are staged through device memory -- both give what the device-pointer entry points give."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(B, 40, 14, 1, seed=B)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    total_bytes = 8 * (nlp.dims.z_total + nlp.dims.c_total + nlp.dims.j_total)
+    assert (total_bytes <= 8 << 20) == (B == 5)  # the two sizes sit on either side of the switch
+    Zd = nlp.upload_Z(batch.Z)
+    c, v = nlp.eval_c_and_jac(Zd, write_constants=True)
+    f, g = nlp.eval_f(Zd), nlp.grad_f(Zd)
+    torch.cuda.synchronize()
+    for rep in range(2):  # the second round reuses the handle's buffers
+        assert np.array_equal(nlp.eval_c_host(batch.Z), c.cpu().numpy())
+        assert np.array_equal(nlp.eval_f_host(batch.Z), f.cpu().numpy())
+        assert np.array_equal(nlp.grad_f_host(batch.Z).reshape(B, -1)[:, : nlp.n_nlp],
+                              g.cpu().numpy().reshape(B, -1)[:, : nlp.n_nlp])
+        vh, vd = nlp.jac_c_host(batch.Z), v.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(nlp.split_vals(vh, b), nlp.split_vals(vd, b))
+        m = nlp.problem_dims(B - 1)[0]
+        D = np.full((m, nlp.n_nlp), np.nan, order="F")
+        nlp.jac_c_dense_host(batch.Z[B - 1], D, B - 1)
+        r, cidx = nlp.jacobian_structure(B - 1)
+        assert np.array_equal(D[r, cidx], nlp.split_vals(vd, B - 1))
