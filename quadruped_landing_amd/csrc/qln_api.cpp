@@ -105,6 +105,8 @@ int upload(T** dst, const T* src, size_t n) {
 int ensure(double** buf, int64_t n) {
     if (*buf) return QLN_OK;
     QLN_HIP(hipMalloc(reinterpret_cast<void**>(buf), std::max<int64_t>(n, 1) * sizeof(double)));
+    // the padding between problems is never written by the kernels: the caller gets zeros there, not stale memory
+    QLN_HIP(hipMemset(*buf, 0, std::max<int64_t>(n, 1) * sizeof(double)));
     return QLN_OK;
 }
 
@@ -464,7 +466,7 @@ int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, u
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_jacobian: null Z");
     if (int rc = check_vals(vals)) return rc;
     if (int rc = bind_device(h)) return rc;
-    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, nullptr, vals, flags, h->stream));
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, nullptr, vals, flags & QLN_JAC_WRITE_CONSTANTS, h->stream));
     return QLN_OK;
 }
 
@@ -473,7 +475,7 @@ int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
     if (!Z || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_constraint_and_jacobian: null pointer");
     if (int rc = check_vals(vals)) return rc;
     if (int rc = bind_device(h)) return rc;
-    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream));
+    QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags & QLN_JAC_WRITE_CONSTANTS, h->stream));
     return QLN_OK;
 }
 
@@ -591,7 +593,7 @@ int qln_eval_constraint_host(qln_handle* h, const double* Z, double* c) {
         if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
         if (int rc = ensure_mapped(&h->m_c, h->dims.c_total)) return rc;
         std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
-        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, h->m_c.dev, nullptr, 0, h->stream));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, h->m_c.dev, nullptr, qln::kLaunchSplit, h->stream));
         QLN_HIP(hipStreamSynchronize(h->stream));
         std::memcpy(c, h->m_c.host, h->dims.c_total * sizeof(double));
         return QLN_OK;
@@ -613,8 +615,8 @@ int qln_eval_constraint_jacobian_host(qln_handle* h, const double* Z, double* va
         if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
         if (int rc = ensure_mapped(&h->m_vals, h->dims.j_total)) return rc;
         std::memcpy(h->m_Z.host, Z, h->dims.z_total * sizeof(double));
-        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, nullptr, h->m_vals.dev, QLN_JAC_WRITE_CONSTANTS,
-                                                h->stream));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, 0, h->p.B, h->m_Z.dev, nullptr, h->m_vals.dev,
+                                                QLN_JAC_WRITE_CONSTANTS | qln::kLaunchSplit, h->stream));
         QLN_HIP(hipStreamSynchronize(h->stream));
         std::memcpy(vals, h->m_vals.host, h->dims.j_total * sizeof(double));
         return QLN_OK;
@@ -644,7 +646,8 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
         if (int rc = ensure_mapped(&h->m_Z, h->dims.z_total)) return rc;
         if (int rc = ensure_mapped(&h->m_vals, h->dims.j_total)) return rc;
         std::memcpy(h->m_Z.host + (int64_t)b * h->dims.z_stride, Z, h->dims.n_nlp * sizeof(double));
-        QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->m_Z.dev, nullptr, h->m_vals.dev, QLN_JAC_WRITE_CONSTANTS, h->stream));
+        QLN_HIP(qln::launch_constraint_jacobian(h->p, b, 1, h->m_Z.dev, nullptr, h->m_vals.dev,
+                                                QLN_JAC_WRITE_CONSTANTS | qln::kLaunchSplit, h->stream));
         QLN_HIP(hipStreamSynchronize(h->stream));
         v = h->m_vals.host + h->j_off[b];
     } else {
@@ -865,6 +868,7 @@ int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
         return fail(QLN_ERR_INVALID_ARGUMENT, "qln_time_constraint_and_jacobian: bad argument");
     if (int rc = check_vals(vals)) return rc;
     if (int rc = bind_device(h)) return rc;
+    flags &= QLN_JAC_WRITE_CONSTANTS;
     std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
     int rc = QLN_OK;
     for (auto& e : ev)

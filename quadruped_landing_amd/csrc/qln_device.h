@@ -120,6 +120,9 @@ __host__ __device__ constexpr int step_block_offset(int k, int N, int k_trans) {
     return (k <= nc) ? 71 * k : 71 * nc + 56 * nj + 57 * (k - nc - nj);
 }
 
+// internal launch flag (bit 0 is QLN_JAC_WRITE_CONSTANTS): prefer latency over throughput for a small batch
+constexpr uint32_t kLaunchSplit = 2u;
+
 // Fused eval_c! + jac_c! over problems [b_begin, b_begin + nb).  c or vals may be null.
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
                                       double* vals, uint32_t flags, hipStream_t stream);

@@ -848,6 +848,16 @@ extern "C" int qln_diag_set_stamps(void* dev_ptr) {
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
                                       double* vals, uint32_t flags, hipStream_t stream) {
     if (nb <= 0 || (!c && !vals)) return hipSuccess;
+    // Latency-bound callers (the host-pointer MOI mode: one problem or a handful) ask for one workgroup per 16-knot
+    // chunk instead of per problem: the launch is then as long as one chunk (profiles/r01_small_batch_split.txt: it
+    // pays below ~256 problems only, so the batched entry points never ask for it).
+    if (flags & kLaunchSplit) {
+        flags &= ~kLaunchSplit;
+        if (nb <= 256 && p.N > 17) {
+            if (vals && p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 16, 2, true, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+            return launch_cj_t<16, 16, 1, false, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        }
+    }
     // Shipping configuration: T=16 (38.4 KB tile, 4 waves per CU, one per SIMD) when the Jacobian is
     // written, T=8 / 8 waves per CU for the constraint-only launch (profiles/r01_variants.txt).
 #ifdef QLN_TUNING
