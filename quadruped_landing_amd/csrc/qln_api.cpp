@@ -81,6 +81,12 @@ struct qln_handle {
     };
     Mapped m_Z, m_c, m_vals, m_f, m_grad;
     bool zero_copy = false;
+    // dense MOI scatter: per problem, where each value of the vals segment goes in the column-major matrix, and the
+    // write-set's explicit zeros (built on first use)
+    struct DenseMap {
+        std::vector<int64_t> at, zeros;
+    };
+    std::vector<DenseMap> dense_map;
     // buffers handed out by qln_vals_alloc_placed
     struct Placed {
         char* va = nullptr;        // reserved virtual range
@@ -662,21 +668,28 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
         QLN_HIP(hipStreamSynchronize(h->stream));
         v = h->h_vals_one.data();
     }
-    std::vector<int32_t> rows(nnz), cols(nnz);
-    if (int rc = qln_jacobian_structure(h, b, rows.data(), cols.data())) return rc;
-    // D[ci, xi[k+1]] .= -I(n) assigns the whole 15x15 block (explicit zeros off the diagonal)
-    int32_t ci[14];
-    cinds_of(N, kt, ci);
-    for (int32_t k = 0; k < N - 1; ++k)
-        for (int32_t c = 0; c < 15; ++c)
-            for (int32_t r = 0; r < 15; ++r)
-                if (r != c) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * (k + 1) + c)] = 0.0;
-    if (h->p.jac_format == QLN_JAC_FORMAT_STRUCTURAL)
-        // D[ci, [xi[k]; ui[k]]] .= J assigns the whole 15x20 block: the entries the structural format leaves out are 0
+    if (h->dense_map.empty()) h->dense_map.resize((size_t)h->dims.B);
+    qln_handle::DenseMap& dm = h->dense_map[(size_t)b];
+    if (dm.at.empty()) {
+        std::vector<int32_t> rows(nnz), cols(nnz);
+        if (int rc = qln_jacobian_structure(h, b, rows.data(), cols.data())) return rc;
+        dm.at.resize(nnz);
+        for (int32_t e = 0; e < nnz; ++e) dm.at[e] = rows[e] + m * (int64_t)cols[e];
+        // D[ci, xi[k+1]] .= -I(n) assigns the whole 15x15 block (explicit zeros off the diagonal)
+        int32_t ci[14];
+        cinds_of(N, kt, ci);
         for (int32_t k = 0; k < N - 1; ++k)
-            for (int32_t c = 0; c < 20; ++c)
-                for (int32_t r = 0; r < 15; ++r) jac[(ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * k + c)] = 0.0;
-    for (int32_t e = 0; e < nnz; ++e) jac[rows[e] + m * (int64_t)cols[e]] = v[e];
+            for (int32_t c = 0; c < 15; ++c)
+                for (int32_t r = 0; r < 15; ++r)
+                    if (r != c) dm.zeros.push_back((ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * (k + 1) + c));
+        if (h->p.jac_format == QLN_JAC_FORMAT_STRUCTURAL)
+            // D[ci, [xi[k]; ui[k]]] .= J assigns the whole 15x20 block: the entries the structural format leaves out are 0
+            for (int32_t k = 0; k < N - 1; ++k)
+                for (int32_t c = 0; c < 20; ++c)
+                    for (int32_t r = 0; r < 15; ++r) dm.zeros.push_back((ci[4] - 1 + 15 * k + r) + m * (int64_t)(20 * k + c));
+    }
+    for (int64_t i : dm.zeros) jac[i] = 0.0;
+    for (int32_t e = 0; e < nnz; ++e) jac[dm.at[e]] = v[e];
     return QLN_OK;
 }
 
