@@ -132,6 +132,23 @@ def main():
                          "memory at setup (HybridNLP.new_vals_placed), falling back to this many timed candidate allocations")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+    # command line the driver uses) as CHILD processes and relay rank 0's JSON line.  Nothing has touched the GPU
+    # yet in this process, and it never will: it only waits.  Under a launcher (WORLD_SIZE set) the two must agree.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
+    if args.gpus > 1 and env_world is None:
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
     # fd 1 when the process group is created), so everything that is not the result goes to stderr: fd 1 is pointed at
     # stderr for the duration of the run and the JSON line is written to the saved descriptor at the end.

@@ -205,14 +205,23 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
  * ~20 % faster when the two halves of the buffer lie in different regions (DESIGN.md section 5,
  * profiles/r01_placement_regions.txt).  This call builds such a buffer with the HIP virtual-memory API: it maps
  * j_total doubles + 64 GiB of physical memory (less if less is free) in 256-MiB chunks behind one virtual range,
- * times the fused launch on windows of that range (Z, c as for qln_eval_constraint_and_jacobian; c is overwritten),
- * keeps the fastest window and returns every chunk outside it to the driver.  Buffers under 1 GiB are mapped as they
- * come.  *vals is at least 2-MiB aligned and holds j_total doubles; constants are not written.  ms_best (may be NULL):
- * launch time on the window kept.  QLN_ERR_HIP if the memory or the virtual-memory API is not available.  Release with
- * qln_vals_free_placed (qln_destroy releases what is left); the virtual range itself stays reserved for the life of
- * the process (its addresses are never reused). */
+ * times the fused launch on windows of that range, keeps the fastest window and returns every chunk outside it to the
+ * driver.  Buffers under 1 GiB are mapped as they come.  Z as for qln_eval_constraint_and_jacobian; c: the constraint
+ * buffer the timed launches write -- it is OVERWRITTEN -- or NULL to have the call use a scratch buffer of its own.
+ * *vals is at least 2-MiB aligned and holds j_total doubles; constants are not written.  ms_best (may be NULL): launch
+ * time on the window kept.  QLN_ERR_HIP if the memory or the virtual-memory API is not available; nothing stays
+ * allocated or mapped after a failure.
+ * Release with qln_vals_free_placed (qln_destroy releases what is left).  Both wait for the whole DEVICE to go idle
+ * before unmapping -- the buffer is plain memory to its users, so work on any stream may still be touching it -- and
+ * report a failing unmap / release instead of hiding it.  The physical memory goes back to the driver; the virtual
+ * range stays reserved for the life of the process, because on ROCm 7.2 an address that has been unmapped keeps
+ * serving accesses through its old translations if it is ever mapped again (bench/vmm_va_reuse.cpp,
+ * profiles/r02_vmm_va_reuse.txt): ~70 GiB of address space per call, of 128 TiB. */
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best);
 int qln_vals_free_placed(qln_handle* h, double* vals);
+/* What the placement scan of a buffer returned by qln_vals_alloc_placed did (each out pointer may be NULL). */
+int qln_vals_placed_info(const qln_handle* h, const double* vals, int64_t* chunk_bytes, int64_t* chunks_scanned,
+                         int64_t* window_first_chunk);
 
 /* Measurement helper for bench.py: runs `warmup` + `iters` launches of the fused hot path on the
  * handle's stream and returns each timed launch's duration from HIP events (milliseconds). */

@@ -5,6 +5,7 @@
 # reading is credible: every method is one ccall.  Usage inside the reference's notebook, after
 # `include("nlp.jl")` etc.:   nlp = HybridNLPHIP(model, obj, init_mode, k_trans, N, xinit, xterm)
 #                              Z_sol, solver = solve(Z0, nlp)            # src/moi.jl:46, unchanged
+using LinearAlgebra        # diag
 using MathOptInterface
 const MOI = MathOptInterface
 const LIBQLN = get(ENV, "QLN_LIB", joinpath(@__DIR__, "..", "..", "quadruped_landing_amd", "csrc", "libqln_hip.so"))

@@ -106,6 +106,7 @@ SIGNATURES = {
     "qln_eval_constraint_jacobian_dense_host": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "qln_vals_alloc_placed": (C.c_int, [_vp, _dp, _dp, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "qln_vals_free_placed": (C.c_int, [_vp, _dp]),
+    "qln_vals_placed_info": (C.c_int, [_vp, _dp, _i64p, _i64p, _i64p]),
     "qln_time_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }
 

@@ -36,6 +36,21 @@ int fail(int code, const std::string& msg) {
 
 int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// Whether a placed buffer's virtual range is handed back (hipMemAddressFree) when the buffer is released.
+// It is NOT: on this stack (ROCm 7.2 user space, the pool's host driver) a virtual address that has been unmapped
+// with hipMemUnmap keeps serving GPU accesses through the translations of its previous mapping, with every call
+// returning hipSuccess -- so an address that was ever unmapped must never be mapped again, neither in place nor
+// after hipMemAddressFree + hipMemAddressReserve (which hands the same addresses out again).  Reproduced without
+// this library or torch by bench/vmm_va_reuse.cpp (profiles/r02_vmm_va_reuse.txt):
+//   reserve R; map chunks A; fill through R; hipMemUnmap(R); map chunks B at R; fill through R
+//     -> every word of A (still alive, inspected through a second mapping) carries B's pattern;
+//   ... hipMemUnmap(R); hipMemAddressFree(R); hipMemAddressReserve -> R again; map B; fill; read back
+//     -> ~0.7 % of the words read back wrong, and A (alive) has been written into.
+// That is what round 1 saw as "writes through stale translations"; it is not a missing synchronisation (the device was
+// idle at every unmap in that sequence, and is here).  Keeping a released buffer's range reserved costs address space
+// only (~70 GiB of 128 TiB per qln_vals_alloc_placed call); the physical memory is returned.
+constexpr bool kReturnVirtualRange = false;
+
 // sizes of src/nlp.jl:48-87
 int32_t m_nlp_of(int32_t N, int32_t kt) { return 18 * N - kt + 16; }
 int32_t nnz_dyn_of(int32_t N, int32_t kt, int32_t fmt) {
@@ -90,9 +105,10 @@ struct qln_handle {
     // buffers handed out by qln_vals_alloc_placed
     struct Placed {
         char* va = nullptr;        // reserved virtual range
-        size_t va_size = 0;
+        size_t va_size = 0;        // bytes reserved at va
         size_t chunk = 0;
         size_t first = 0;          // first chunk still mapped
+        size_t scanned = 0;        // chunks the placement scan looked at
         std::vector<hipMemGenericAllocationHandle_t> chunks;  // the mapped ones, in order
         double* vals = nullptr;
     };
@@ -256,31 +272,48 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     return QLN_OK;
 }
 
-static void release_placed(qln_handle::Placed& p) {
+// Gives a placed buffer back: unmap every chunk still mapped, release the physical handles, free the virtual range.
+// The caller has synchronised the DEVICE (not just the handle's stream: the buffer was handed out as plain memory, so
+// work on any stream -- torch's current one, a stream set later with qln_set_stream -- may have touched it).  Every
+// return code is looked at; the first failure is reported through qln_last_error and the rest is still attempted.
+static int release_placed(qln_handle::Placed& p) {
+    hipError_t first = hipSuccess;
+    const char* what = nullptr;
+    auto note = [&](hipError_t e, const char* w) {
+        if (e != hipSuccess && first == hipSuccess) {
+            first = e;
+            what = w;
+        }
+    };
     for (size_t i = 0; i < p.chunks.size(); ++i) {
-        (void)hipMemUnmap(p.va + (p.first + i) * p.chunk, p.chunk);
-        (void)hipMemRelease(p.chunks[i]);
+        note(hipMemUnmap(p.va + (p.first + i) * p.chunk, p.chunk), "hipMemUnmap");
+        note(hipMemRelease(p.chunks[i]), "hipMemRelease");
     }
     p.chunks.clear();
-    // The virtual range is deliberately NOT handed back (hipMemAddressFree): a later reservation can get the same
-    // addresses, and on ROCm 7.2 kernels were then seen writing through stale translations into the physical memory
-    // the range used to map (tests/test_gpu_parity.py::test_region_placed_buffer_...).  Address space is plentiful
-    // (a buffer's range is ~40 GiB of 128 TiB); the physical memory is what is released here.
+    if (p.va && kReturnVirtualRange) note(hipMemAddressFree(p.va, p.va_size), "hipMemAddressFree");
     p.va = nullptr;
+    if (first != hipSuccess) return fail(QLN_ERR_HIP, std::string("releasing a placed buffer: ") + what + ": " + hipGetErrorString(first));
+    return QLN_OK;
 }
 
 int qln_destroy(qln_handle* h) {
     if (!h) return QLN_OK;
     (void)hipSetDevice(h->device);
-    if (!h->placed.empty()) (void)hipStreamSynchronize(h->stream);  // nothing may still be writing to memory about to be unmapped
-    for (auto& p : h->placed) release_placed(p);
+    int rc = QLN_OK;
+    if (!h->placed.empty()) {
+        // nothing on any stream may still be reading or writing memory about to be unmapped
+        if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess)
+            rc = fail(QLN_ERR_HIP, std::string("qln_destroy: hipDeviceSynchronize: ") + hipGetErrorString(e));
+        for (auto& p : h->placed)
+            if (int r = release_placed(p); r != QLN_OK && rc == QLN_OK) rc = r;
+    }
     for (qln_handle::Mapped* m : {&h->m_Z, &h->m_c, &h->m_vals, &h->m_f, &h->m_grad})
         if (m->host) (void)hipHostFree(m->host);
     void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete h;
-    return QLN_OK;
+    return rc;
 }
 
 int qln_set_stream(qln_handle* h, void* hip_stream) {
@@ -719,7 +752,7 @@ static int time_fused(qln_handle* h, const double* Z, double* c, double* vals, i
 
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best) {
     if (int rc = check_handle(h)) return rc;
-    if (!Z || !c || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_alloc_placed: null pointer");
+    if (!Z || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_alloc_placed: null pointer");
     *vals = nullptr;
     if (int rc = bind_device(h)) return rc;
     hipMemAllocationProp prop = {};
@@ -728,7 +761,12 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
     prop.location.id = h->device;
     size_t gran = 0;
     QLN_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    const size_t chunk = round_up((int64_t)256 << 20, (int64_t)gran);   // physical chunks; 2 GiB and more fault on ROCm 7.2
+    // Physical chunks of 256 MiB.  Larger ones buy nothing (launch times are the same from 2 MiB to 1 GiB,
+    // profiles/r01_vmm_placement.txt) and chunks of 2 GiB and more are not usable on ROCm 7.2: a range built as
+    // hipMemAddressReserve(8 GiB) + 4 x {hipMemCreate(2 GiB), hipMemMap} + hipMemSetAccess(whole range) raised a GPU
+    // memory access fault under the first kernel that wrote it (bench/vmm_placement.cpp, round 1), with every call
+    // returning hipSuccess -- the same program is clean with chunks of 1 GiB and less.
+    const size_t chunk = round_up((int64_t)256 << 20, (int64_t)gran);
     const size_t bytes = (size_t)h->dims.j_total * 8;
     const size_t need = (bytes + chunk - 1) / chunk;                     // chunks under vals
     const size_t region = ((size_t)32 << 30) / chunk;                    // period of the speed classes, in chunks
@@ -738,125 +776,136 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
     const size_t budget = free_b / 10 * 9 / chunk;                       // chunks this call may hold at once
     if (budget < need + 1) return fail(QLN_ERR_HIP, "qln_vals_alloc_placed: not enough free device memory");
 
-    // Physical memory: a slab of consecutive 256-MiB allocations (consecutive allocations are consecutive in device
-    // memory as far as the launch times can tell), long enough for the layouts tried below.
-    // two region lengths: the slab then contains two boundaries, i.e. two chances of a clean straddling window
-    size_t nslab = small ? need : std::min(budget, need + 2 * region + 1);
-    std::vector<hipMemGenericAllocationHandle_t> slab;
-    auto drop_slab = [&](const std::vector<char>& keep) {
-        for (size_t i = 0; i < slab.size(); ++i)
-            if (keep.empty() || !keep[i]) (void)hipMemRelease(slab[i]);
+    // Everything this call holds until it has succeeded.  abandon() is the one way out on failure: synchronise the
+    // device, unmap what is mapped, release every handle, hand the range back, free the scratch constraint buffer.
+    std::vector<hipMemGenericAllocationHandle_t> slab;   // consecutive physical chunks (consecutive allocations are
+    std::vector<char> mapped;                            // consecutive in device memory as far as launch times can tell)
+    char* va = nullptr;
+    size_t va_size = 0;
+    double* scratch_c = nullptr;
+    auto abandon = [&](int code) {
+        (void)hipDeviceSynchronize();
+        for (size_t i = 0; i < slab.size(); ++i) {
+            if (i < mapped.size() && mapped[i]) (void)hipMemUnmap(va + i * chunk, chunk);
+            if (slab[i]) (void)hipMemRelease(slab[i]);
+        }
+        if (va && kReturnVirtualRange) (void)hipMemAddressFree(va, va_size);
+        if (scratch_c) (void)hipFree(scratch_c);
+        return code;
     };
+    auto fail_hip = [&](const char* what, hipError_t e) {
+        return abandon(fail(QLN_ERR_HIP, std::string("qln_vals_alloc_placed: ") + what + ": " + hipGetErrorString(e)));
+    };
+
+    // the timed launches write a constraint vector: the caller's c if one is given (it is overwritten), else a scratch
+    if (!c) {
+        if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch_c), (size_t)h->dims.c_total * 8); e != hipSuccess)
+            return fail_hip("hipMalloc(scratch c)", e);
+        c = scratch_c;
+    }
+    // two region lengths beyond the buffer: the slab then contains two boundaries, i.e. two chances of a clean
+    // straddling window
+    size_t nslab = small ? need : std::min(budget, need + 2 * region + 1);
     for (size_t i = 0; i < nslab; ++i) {
         hipMemGenericAllocationHandle_t hd;
         const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
         if (e != hipSuccess) {
             if (slab.size() >= need + 1) break;  // less than planned, still usable
-            drop_slab({});
-            return fail(QLN_ERR_HIP, std::string("qln_vals_alloc_placed: hipMemCreate: ") + hipGetErrorString(e));
+            return fail_hip("hipMemCreate", e);
         }
         slab.push_back(hd);
     }
     nslab = slab.size();
-    hipMemAccessDesc ad = {};
-    ad.location = prop.location;
-    ad.flags = hipMemAccessFlagsProtReadWrite;
+    mapped.assign(nslab, 0);
+    va_size = nslab * chunk;
+    {
+        void* p = nullptr;
+        if (hipError_t e = hipMemAddressReserve(&p, va_size, 0, nullptr, 0); e != hipSuccess) return fail_hip("hipMemAddressReserve", e);
+        va = static_cast<char*>(p);
+    }
+    for (size_t i = 0; i < nslab; ++i) {
+        if (hipError_t e = hipMemMap(va + i * chunk, chunk, 0, slab[i], 0); e != hipSuccess) return fail_hip("hipMemMap", e);
+        mapped[i] = 1;
+    }
+    {
+        hipMemAccessDesc ad = {};
+        ad.location = prop.location;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipError_t e = hipMemSetAccess(va, va_size, &ad, 1); e != hipSuccess) return fail_hip("hipMemSetAccess", e);
+    }
 
-    // a virtual range with slab chunk pick[j] behind its j-th chunk
-    struct View {
-        char* va = nullptr;
-        size_t n = 0;
-    };
-    auto map_view = [&](View& v, const std::vector<size_t>& pick) -> hipError_t {
-        if (!v.va) {
-            void* p = nullptr;
-            if (hipError_t e = hipMemAddressReserve(&p, pick.size() * chunk, 0, nullptr, 0); e != hipSuccess) return e;
-            v.va = static_cast<char*>(p);
-        }
-        v.n = pick.size();
-        for (size_t j = 0; j < pick.size(); ++j)
-            if (hipError_t e = hipMemMap(v.va + j * chunk, chunk, 0, slab[pick[j]], 0); e != hipSuccess) return e;
-        return hipMemSetAccess(v.va, v.n * chunk, &ad, 1);
-    };
-    auto unmap_view = [&](View& v) {
-        if (v.va && v.n) (void)hipMemUnmap(v.va, v.n * chunk);
-        v.n = 0;
-    };
-    auto fail_hip = [&](const char* what, hipError_t e) {
-        drop_slab({});
-        return fail(QLN_ERR_HIP, std::string("qln_vals_alloc_placed: ") + what + ": " + hipGetErrorString(e));
-    };
-
-    std::vector<size_t> final_pick;
-    View final_view;
-    size_t final_off = 0;  // chunks
-    float best = 0.f;
-    if (small) {
-        final_pick.resize(need);
-        for (size_t j = 0; j < need; ++j) final_pick[j] = j;
-        if (hipError_t e = map_view(final_view, final_pick); e != hipSuccess) return fail_hip("map", e);
-        if (int rc = time_fused(h, Z, c, reinterpret_cast<double*>(final_view.va), 1, 2, &best)) {
-            drop_slab({});
-            return rc;
-        }
-    } else {
-        // The slab as it lies, the fused launch timed on its windows: the best one straddles a region boundary (XCDs
-        // 0-3 write one region, XCDs 4-7 the next).  Giving every XCD's range a region of its own (ranges 16 GiB
-        // apart) was tried as a second layout: 1.10 ms against 1.08-1.10 ms for the best window, so it is not built.
-        View lin;
-        const size_t nlin = nslab;
-        std::vector<size_t> pick(nlin);
-        for (size_t j = 0; j < nlin; ++j) pick[j] = j;
-        if (hipError_t e = map_view(lin, pick); e != hipSuccess) return fail_hip("map", e);
-        size_t best_off = 0;
-        float t_lin = 1e30f;
+    // The slab as it lies, the fused launch timed on its windows: the best one straddles a region boundary (XCDs 0-3
+    // write one region, XCDs 4-7 the next).  Giving every XCD's range a region of its own (ranges 16 GiB apart) was
+    // tried as a second layout: 1.10 ms against 1.08-1.10 ms for the best window, so it is not built.
+    size_t best_off = 0;  // chunks
+    float best = 1e30f;
+    {
         auto probe = [&](size_t off) {
             float ms = 0.f;
-            const int rc = time_fused(h, Z, c, reinterpret_cast<double*>(lin.va + off * chunk), 1, 2, &ms);
-            if (rc == QLN_OK && ms < t_lin) {
-                t_lin = ms;
+            const int rc = time_fused(h, Z, c, reinterpret_cast<double*>(va + off * chunk), 1, 2, &ms);
+            if (rc == QLN_OK && ms < best) {
+                best = ms;
                 best_off = off;
             }
             return rc;
         };
         int rc = QLN_OK;
-        for (size_t off = 0; off + need <= nlin && rc == QLN_OK; off += 4) rc = probe(off);  // 1-GiB steps
-        const size_t centre = best_off;
-        for (int k = -3; k <= 3 && rc == QLN_OK; ++k) {
-            const int64_t off = (int64_t)centre + k;
-            if (k != 0 && off >= 0 && (size_t)off + need <= nlin) rc = probe((size_t)off);
+        if (small) {
+            rc = probe(0);
+        } else {
+            for (size_t off = 0; off + need <= nslab && rc == QLN_OK; off += 4) rc = probe(off);  // 1-GiB steps
+            const size_t centre = best_off;
+            for (int k = -3; k <= 3 && rc == QLN_OK; ++k) {
+                const int64_t off = (int64_t)centre + k;
+                if (k != 0 && off >= 0 && (size_t)off + need <= nslab) rc = probe((size_t)off);
+            }
         }
-        if (rc != QLN_OK) {
-            unmap_view(lin);
-            drop_slab({});
-            return rc;
-        }
-        // everything outside the window is unmapped; the window keeps its addresses
-        final_pick.resize(need);
-        for (size_t j = 0; j < need; ++j) final_pick[j] = best_off + j;
-        for (size_t j = 0; j < nlin; ++j)
-            if (j < best_off || j >= best_off + need) (void)hipMemUnmap(lin.va + j * chunk, chunk);
-        if (getenv("QLN_PLACEMENT_VERBOSE"))
-            fprintf(stderr, "qln_vals_alloc_placed: %zu chunks of %zu MiB scanned; best window at chunk %zu: %.3f ms\n", nlin,
-                    chunk >> 20, best_off, t_lin);
-        final_view = lin;
-        final_off = best_off;
-        best = t_lin;
+        if (rc != QLN_OK) return abandon(rc);
     }
-    // give back every chunk that is not under the buffer
-    std::vector<char> keep(nslab, 0);
-    for (size_t j : final_pick) keep[j] = 1;
-    drop_slab(keep);
+    // Every chunk outside the window goes back to the driver; the window keeps its addresses.  time_fused waited for
+    // each of its launches, but nothing is assumed: the device is idle before the first unmap.
+    if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return fail_hip("hipDeviceSynchronize", e);
+    for (size_t i = 0; i < nslab; ++i) {
+        if (i >= best_off && i < best_off + need) continue;
+        if (hipError_t e = hipMemUnmap(va + i * chunk, chunk); e != hipSuccess) return fail_hip("hipMemUnmap", e);
+        mapped[i] = 0;
+    }
+    for (size_t i = 0; i < nslab; ++i) {
+        if (i >= best_off && i < best_off + need) continue;
+        const hipError_t e = hipMemRelease(slab[i]);
+        slab[i] = nullptr;  // released (or lost): abandon() must not release it again
+        if (e != hipSuccess) return fail_hip("hipMemRelease", e);
+    }
+    if (scratch_c) {
+        const hipError_t e = hipFree(scratch_c);
+        scratch_c = nullptr;
+        if (e != hipSuccess) return fail_hip("hipFree(scratch c)", e);
+    }
     qln_handle::Placed P;
     P.chunk = chunk;
-    P.va = final_view.va;
-    P.first = final_off;
-    for (size_t j : final_pick) P.chunks.push_back(slab[j]);
-    P.vals = reinterpret_cast<double*>(final_view.va + final_off * chunk);
+    P.va = va;
+    P.va_size = va_size;
+    P.first = best_off;
+    P.chunks.assign(slab.begin() + (long)best_off, slab.begin() + (long)(best_off + need));
+    P.vals = reinterpret_cast<double*>(va + best_off * chunk);
+    P.scanned = nslab;
     h->placed.push_back(P);
     *vals = P.vals;
     if (ms_best) *ms_best = best;
     return QLN_OK;
+}
+
+int qln_vals_placed_info(const qln_handle* h, const double* vals, int64_t* chunk_bytes, int64_t* chunks_scanned,
+                         int64_t* window_first_chunk) {
+    if (int rc = check_handle(h)) return rc;
+    for (const auto& p : h->placed)
+        if (p.vals == vals) {
+            if (chunk_bytes) *chunk_bytes = (int64_t)p.chunk;
+            if (chunks_scanned) *chunks_scanned = (int64_t)p.scanned;
+            if (window_first_chunk) *window_first_chunk = (int64_t)p.first;
+            return QLN_OK;
+        }
+    return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_placed_info: not a buffer of this handle");
 }
 
 int qln_vals_free_placed(qln_handle* h, double* vals) {
@@ -864,10 +913,12 @@ int qln_vals_free_placed(qln_handle* h, double* vals) {
     if (int rc = bind_device(h)) return rc;
     for (size_t i = 0; i < h->placed.size(); ++i)
         if (h->placed[i].vals == vals) {
-            (void)hipStreamSynchronize(h->stream);
-            release_placed(h->placed[i]);
+            // the whole device, not the handle's stream: the buffer was handed out as plain memory and any stream may
+            // have work on it (torch's current stream; a stream set with qln_set_stream after the last launch)
+            QLN_HIP(hipDeviceSynchronize());
+            const int rc = release_placed(h->placed[i]);
             h->placed.erase(h->placed.begin() + (long)i);
-            return QLN_OK;
+            return rc;
         }
     return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_free_placed: not a buffer of this handle");
 }

@@ -1,13 +1,18 @@
-"""Multi-GPU: one process per GPU, problems sharded by contiguous batch ranges, no data-path
+"""Multi-GPU, one process per GPU: problems sharded by contiguous batch ranges, no data-path
 collective; a single gather of the per-problem results (f, c) to rank 0 at the end
 (BASELINE.json north_star).  Jacobian values stay resident on the GPU that
 produced them: at config 5 they are 6.2 GB per rank, ~18x the kernel time over xGMI.
 
-Backend-agnostic (`nccl` = RCCL on the GPUs, `gloo` on CPU for the tests).
+Backend-agnostic (`nccl` = RCCL on the GPUs, `gloo` on CPU for the tests).  The same exchange from a
+host that has no torch.distributed (the reference's Julia, a C program) is include/qln_multi.h.
+
+Shards are ragged in general: a rank's constraint buffer holds sum_b round_up(18N - k_trans(b) + 16, align)
+doubles, which differs between ranks as soon as k_trans varies per problem (BASELINE.json configs[3]) or the
+batch does not divide by the world size -- so the gather exchanges the lengths first.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import List, Optional, Tuple
 
 
 def shard_range(n_problems: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -19,20 +24,59 @@ def shard_range(n_problems: int, rank: int, world_size: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_to_root(t, dst: int = 0, group=None):
-    """Gather equally-sized 1-D tensors to `dst`; returns the list on dst, None elsewhere."""
+def gather_sizes(numel: int, like, group=None) -> List[int]:
+    """Every rank's element count, on every rank (one small all_gather)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(numel)], dtype=torch.int64, device=like.device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    return [int(s.item()) for s in sizes]
+
+
+def gather_to_root(t, dst: int = 0, group=None) -> Optional[list]:
+    """Gather 1-D tensors -- of possibly different lengths -- to group rank `dst`.
+    Returns the list of per-rank tensors on dst, None elsewhere.
+
+    Equal lengths: one `gather`.  Unequal: the root posts one receive per peer and every peer one send, as one
+    batch (ncclGroupStart/End under RCCL -- exactly what ncclGather does inside), so nothing is padded or copied.
+    """
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
         return [t]
     world = dist.get_world_size(group)
-    if dist.get_rank(group) == dst:
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.gather(t, gather_list=out, dst=dst, group=group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return [t]
+    t = t.contiguous().reshape(-1)
+    sizes = gather_sizes(t.numel(), t, group)
+    if all(s == sizes[0] for s in sizes):
+        if rank == dst:
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.gather(t, gather_list=out, dst=_global(dst, group), group=group)
+            return out
+        dist.gather(t, gather_list=None, dst=_global(dst, group), group=group)
+        return None
+    if rank == dst:
+        out = [t if r == dst else torch.empty(sizes[r], dtype=t.dtype, device=t.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, out[r], _global(r, group), group) for r in range(world) if r != dst and sizes[r] > 0]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
         return out
-    dist.gather(t, gather_list=None, dst=dst, group=group)
+    if t.numel() > 0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, _global(dst, group), group)]):
+            w.wait()
     return None
+
+
+def _global(group_rank: int, group) -> int:
+    import torch.distributed as dist
+
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
 def gather_results(f, c, dst: int = 0, group=None):

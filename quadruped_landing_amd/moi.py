@@ -42,7 +42,16 @@ def eval_constraint_jacobian(prob, vec, x, b: int = 0):
     jac = np.asarray(vec).reshape((m_nlp, n_nlp), order="F")
     if not np.shares_memory(jac, vec):
         raise ValueError("vec must be a contiguous float64 buffer")
-    prob.jac_c_dense_host(np.asarray(x, dtype=np.float64).reshape(-1)[:n_nlp] if prob.B == 1 else x, jac, b)
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if x.size == n_nlp:                     # problem b's own decision vector
+        xb = x
+    elif x.size == prob.B * prob.z_stride:  # the whole batch in the handle's layout: take problem b's slice
+        xb = x.reshape(prob.B, prob.z_stride)[b, :n_nlp]
+    elif x.size == prob.B * n_nlp:
+        xb = x.reshape(prob.B, n_nlp)[b]
+    else:
+        raise ValueError(f"x has {x.size} entries; expected n_nlp = {n_nlp} or the whole batch")
+    prob.jac_c_dense_host(xb, jac, b)
     return None
 
 

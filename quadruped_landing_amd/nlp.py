@@ -102,8 +102,14 @@ class _PlacedBuffer:
     def __del__(self):
         h = getattr(self._nlp, "_h", None)
         if h and self._ptr:
+            # qln_vals_free_placed waits for the whole device (the tensor may have been used on any stream) and
+            # reports a failing unmap / release; a destructor cannot raise, so a failure becomes a warning
             try:
-                _lib.lib().qln_vals_free_placed(h, self._ptr)
+                rc = _lib.lib().qln_vals_free_placed(h, self._ptr)
+                if rc != _lib.QLN_OK:
+                    import warnings
+
+                    warnings.warn(f"qln_vals_free_placed failed ({rc}): {_lib.lib().qln_last_error().decode()}")
             except Exception:
                 pass
             self._ptr = 0
@@ -245,16 +251,24 @@ class HybridNLP:
     def new_vals(self):
         return _torch().zeros(self.dims.j_total, dtype=_torch().float64, device=self._dev())
 
-    def new_vals_regions(self, Z, c):
+    def placed_info(self, vals):
+        """(chunk_bytes, chunks_scanned, window_first_chunk) of a buffer made by new_vals_regions."""
+        a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().qln_vals_placed_info(self._h, vals.data_ptr(), C.byref(a), C.byref(b), C.byref(c_)))
+        return a.value, b.value, c_.value
+
+    def new_vals_regions(self, Z, c=None):
         """The Jacobian buffer placed across two 32-GiB regions of device memory (qln_vals_alloc_placed: HIP
         virtual-memory API, the fused launch timed on windows of a j_total + 32 GiB range, the fastest window kept and
         everything else released).  Returns (vals, ms) -- ms = launch time on the window kept.  Raises QlnError if the
         device has not got j_total*8 + ~33 GiB free or the virtual-memory API fails."""
         t = _torch()
         self._check(Z, self.dims.z_total, "Z")
-        self._check(c, self.dims.c_total, "c")
+        if c is not None:  # overwritten by the timed launches; None = the library uses a scratch buffer of its own
+            self._check(c, self.dims.c_total, "c")
         ptr, ms = C.c_void_p(), C.c_float()
-        _lib.check(_lib.lib().qln_vals_alloc_placed(self._h, Z.data_ptr(), c.data_ptr(), C.byref(ptr), C.byref(ms)))
+        _lib.check(_lib.lib().qln_vals_alloc_placed(self._h, Z.data_ptr(), None if c is None else c.data_ptr(),
+                                                    C.byref(ptr), C.byref(ms)))
         vals = t.as_tensor(_PlacedBuffer(self, ptr.value, int(self.dims.j_total)), device=self._dev())
         return vals, float(ms.value)
 
@@ -531,3 +545,28 @@ def _variable_bounds(N: int, quirk_Q6: bool):
 def variable_bounds_forces(N: int):
     """The bounds the comment in src/moi.jl:63 describes (F1y, F2y >= 0) -- not what the reference does."""
     return _variable_bounds(N, False)
+
+
+def ipopt_initial_point(Z0, x_l, x_u, *, bound_push: float = 1e-2, bound_frac: float = 1e-2,
+                        bound_relax_factor: float = 1e-8, constr_viol_tol: float = 1e-6):
+    """The point at which Ipopt 3.13 evaluates iteration 0 when `solve()` (src/moi.jl:46-103) hands it `Z0` and the
+    variable bounds: Ipopt first relaxes every finite bound by min(constr_viol_tol, bound_relax_factor*max(1,|b|))
+    and then pushes the starting point inside the relaxed bounds by bound_push / bound_frac (Ipopt options of the
+    same names at their defaults; `solve()` sets constr_viol_tol = c_tol = 1e-6).  With `variable_bounds(N)` -- quirk
+    Q6 included -- this reproduces the iteration-0 objective the notebook printed, 1.8380701e+00
+    (src/main.ipynb:232): known answer KA6."""
+    x = np.array(Z0, dtype=np.float64, copy=True)
+    x_l, x_u = np.asarray(x_l, dtype=np.float64), np.asarray(x_u, dtype=np.float64)
+    has_l, has_u = np.isfinite(x_l), np.isfinite(x_u)
+    with np.errstate(invalid="ignore"):
+        lo = np.where(has_l, x_l - np.minimum(constr_viol_tol, bound_relax_factor * np.maximum(1.0, np.abs(x_l))), x_l)
+        up = np.where(has_u, x_u + np.minimum(constr_viol_tol, bound_relax_factor * np.maximum(1.0, np.abs(x_u))), x_u)
+        p_l = bound_push * np.maximum(1.0, np.abs(lo))
+        p_u = bound_push * np.maximum(1.0, np.abs(up))
+        both = has_l & has_u
+        frac = bound_frac * (up - lo)
+        p_l = np.where(both, np.minimum(p_l, frac), p_l)
+        p_u = np.where(both, np.minimum(p_u, frac), p_u)
+        x = np.where(has_l, np.maximum(x, lo + p_l), x)
+        x = np.where(has_u, np.minimum(x, up - p_u), x)
+    return x

@@ -1,5 +1,8 @@
 """Shared helpers for the parity tests: run the oracle on a LandingBatch with the same
 strides/offsets as the product handle, and compare with a stated tolerance."""
+import os
+import subprocess
+
 import numpy as np
 
 from oracle import oracle as O
@@ -29,3 +32,24 @@ def rel_err(a, b, floor=0.0):
     with np.errstate(divide="ignore", invalid="ignore"):
         r = np.where(d == 0, 0.0, d / s)
     return float(r.max()) if r.size else 0.0
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_c_host(out_dir):
+    """gcc-compile tests/host_c/moi_host.c against include/qln_evaluator.h and libqln_hip.so."""
+    csrc = os.path.join(ROOT, "quadruped_landing_amd", "csrc")
+    exe = os.path.join(str(out_dir), "moi_host")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host_c", "moi_host.c"), "-L", csrc, "-lqln_hip", "-lm",
+                           f"-Wl,-rpath,{csrc}", "-o", exe])
+    return exe
+
+
+def write_problem_file(path, nb, Z):
+    m = nb.model
+    with open(path, "w") as fh:
+        fh.write(f"{nb.N} {int(nb.k_trans[0])} {int(nb.init_mode[0])}\n")
+        for arr in ([m.g, m.mb, m.mf, m.lb, m.l1, m.l2], nb.x0[0], nb.xf[0], np.asarray(nb.obj).reshape(-1), Z):
+            fh.write(" ".join(repr(float(x)) for x in np.asarray(arr).reshape(-1)) + "\n")

@@ -1,0 +1,145 @@
+/* moi_host.c -- the reference-side binding's call shape, from a host that is neither Python nor (for lack of a
+ * Julia binary in this pipeline) Julia: a plain C program making exactly the call sequence of
+ * integration/julia/HybridNLPHIP.jl, which binds /root/reference/src/moi.jl:1-33, for ONE landing problem:
+ *
+ *   constructor      qln_create(&desc)  ->  qln_problem_dims  ->  qln_constraint_bounds        (src/nlp.jl:34-87)
+ *   eval_objective   qln_eval_objective_host(x) -> f                                            (src/moi.jl:1-3)
+ *   eval_objective_gradient   qln_eval_objective_gradient_host(x, grad[n_nlp])                  (src/moi.jl:5-8)
+ *   eval_constraint  qln_eval_constraint_host(x, g[m_nlp])                                      (src/moi.jl:10-13)
+ *   eval_constraint_jacobian, dense   qln_eval_constraint_jacobian_dense_host(0, x, vec[m_nlp*n_nlp])  (:15-24)
+ *   eval_constraint_jacobian, sparse  qln_eval_constraint_jacobian_host(x, vec[nnz])
+ *   jacobian_structure                qln_jacobian_structure(0, rows, cols)                     (src/moi.jl:31-33)
+ *   finalizer        qln_destroy
+ *
+ * Buffers are caller-malloc'd with exactly the sizes Ipopt hands the callbacks (m_nlp, n_nlp, m_nlp*n_nlp, nnz): the
+ * library must not write a byte beyond them (guard words are checked).  The dense matrix is pre-filled with a
+ * sentinel: only jac_c!'s write-set may change.
+ *
+ * usage: moi_host <problem file>   (text: N k_trans init_mode / g mb mf lb l1 l2 / x0[15] / xf[15] / cost[N*41] / x[n_nlp])
+ * prints  key=value  lines; exit code 0 = every call returned QLN_OK and no guard word was touched.
+ * build:  gcc -std=c11 -O1 -I include tests/host_c/moi_host.c -L quadruped_landing_amd/csrc -lqln_hip -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qln_evaluator.h"
+
+#define GUARD 4
+static const double kGuard = -7.25e300, kSentinel = 1.2345678e250;
+
+static double* guarded(size_t n, double fill) {
+    double* p = (double*)malloc((n + 2 * GUARD) * sizeof(double));
+    if (!p) exit(3);
+    for (size_t i = 0; i < n + 2 * GUARD; ++i) p[i] = (i < GUARD || i >= n + GUARD) ? kGuard : fill;
+    return p + GUARD;
+}
+static int guards_intact(const double* p, size_t n) {
+    for (int i = 1; i <= GUARD; ++i)
+        if (p[-i] != kGuard || p[n + i - 1] != kGuard) return 0;
+    return 1;
+}
+static void read_doubles(FILE* f, double* dst, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (fscanf(f, "%lf", &dst[i]) != 1) {
+            fprintf(stderr, "moi_host: short problem file\n");
+            exit(3);
+        }
+}
+#define QK(call)                                                              \
+    do {                                                                      \
+        int rc_ = (call);                                                     \
+        if (rc_ != QLN_OK) {                                                  \
+            printf("error=%s -> %d: %s\n", #call, rc_, qln_last_error());     \
+            return 1;                                                         \
+        }                                                                     \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    FILE* fp = fopen(argv[1], "r");
+    if (!fp) return 2;
+    int N, k_trans, init_mode;
+    if (fscanf(fp, "%d %d %d", &N, &k_trans, &init_mode) != 3) return 3;
+    double mdl[6], x0[15], xf[15];
+    read_doubles(fp, mdl, 6);
+    read_doubles(fp, x0, 15);
+    read_doubles(fp, xf, 15);
+    double* cost = (double*)malloc((size_t)N * QLN_COST_STRIDE * sizeof(double));
+    read_doubles(fp, cost, (size_t)N * QLN_COST_STRIDE);
+    const int n_nlp = 20 * N - 5;
+    double* x = guarded((size_t)n_nlp, 0.0);
+    read_doubles(fp, x, (size_t)n_nlp);
+    fclose(fp);
+
+    /* HybridNLPHIP(model, obj, init_mode, k_trans, N, x0, xf): B = 1, defaults for stride / alignment */
+    int32_t kt = k_trans, im = init_mode;
+    qln_batch_desc d;
+    memset(&d, 0, sizeof d);
+    d.B = 1;
+    d.N = N;
+    d.model.g = mdl[0], d.model.mb = mdl[1], d.model.mf = mdl[2], d.model.lb = mdl[3], d.model.l1 = mdl[4], d.model.l2 = mdl[5];
+    d.k_trans = &kt, d.init_mode = &im, d.x0 = x0, d.xf = xf, d.cost = cost, d.cost_batch = 1;
+    d.z_stride = 0, d.align = 0, d.jac_format = QLN_JAC_FORMAT_DENSE_BLOCKS;
+    qln_handle* h = NULL;
+    QK(qln_create(&d, 0, &h));
+    int32_t m_nlp = 0, nnz = 0;
+    QK(qln_problem_dims(h, 0, &m_nlp, &nnz));
+    qln_dims dims;
+    QK(qln_get_dims(h, &dims));
+    printf("version=%s\nn_nlp=%d\nm_nlp=%d\nnnz=%d\n", qln_version(), dims.n_nlp, m_nlp, nnz);
+    /* a B = 1 handle has no padding: the totals ARE the reference's sizes, so Ipopt-owned buffers fit as they are */
+    printf("totals_match=%d\n", dims.z_total == n_nlp && dims.c_total == m_nlp && dims.j_total == nnz);
+    double* lb = guarded((size_t)m_nlp, 1.0);
+    double* ub = guarded((size_t)m_nlp, 1.0);
+    QK(qln_constraint_bounds(h, 0, lb, ub));
+    int n_eq = 0, n_ineq = 0;
+    for (int i = 0; i < m_nlp; ++i) (lb[i] == 0.0 && ub[i] == 0.0) ? ++n_eq : (lb[i] == 0.0 && isinf(ub[i]) ? ++n_ineq : 0);
+    printf("n_eq=%d\nn_ineq=%d\n", n_eq, n_ineq);
+
+    /* MOI.eval_objective / eval_objective_gradient / eval_constraint */
+    double f = 0.0;
+    QK(qln_eval_objective_host(h, x, &f));
+    double* grad = guarded((size_t)n_nlp, kSentinel);
+    QK(qln_eval_objective_gradient_host(h, x, grad));
+    double* g = guarded((size_t)m_nlp, kSentinel);
+    QK(qln_eval_constraint_host(h, x, g));
+    double viol = 0.0, min_ineq = INFINITY, gsum = 0.0;
+    for (int i = 0; i < n_eq; ++i) viol = fmax(viol, fabs(g[i]));
+    for (int i = n_eq; i < m_nlp; ++i) min_ineq = fmin(min_ineq, g[i]);
+    int grad_written = 0;
+    for (int i = 0; i < n_nlp; ++i) grad_written += (grad[i] != kSentinel), gsum += grad[i];
+    printf("f=%.17g\nmax_abs_c_eq=%.17g\nmin_c_ineq=%.17g\ngrad_written=%d\ngrad_sum=%.17g\n", f, viol, min_ineq, grad_written, gsum);
+
+    /* MOI.eval_constraint_jacobian, dense (use_sparse_jacobian = false): Ipopt's m_nlp*n_nlp buffer, column-major */
+    const size_t nd = (size_t)m_nlp * (size_t)n_nlp;
+    double* jac = guarded(nd, kSentinel);
+    QK(qln_eval_constraint_jacobian_dense_host(h, 0, x, jac));
+    long written = 0, nonzero = 0;
+    for (size_t i = 0; i < nd; ++i)
+        if (jac[i] != kSentinel) ++written, nonzero += (jac[i] != 0.0);
+    printf("dense_write_set=%ld\ndense_nonzero=%ld\n", written, nonzero);
+
+    /* ... and sparse (use_sparse_jacobian = true): nnz values in the order of jacobian_structure */
+    double* vals = guarded((size_t)nnz, kSentinel);
+    QK(qln_eval_constraint_jacobian_host(h, x, vals));
+    int32_t* rows = (int32_t*)malloc((size_t)nnz * sizeof(int32_t));
+    int32_t* cols = (int32_t*)malloc((size_t)nnz * sizeof(int32_t));
+    QK(qln_jacobian_structure(h, 0, rows, cols));
+    long agree = 0, in_range = 0;
+    for (int e = 0; e < nnz; ++e) {
+        if (rows[e] < 0 || rows[e] >= m_nlp || cols[e] < 0 || cols[e] >= n_nlp) continue;
+        ++in_range;
+        agree += (jac[(size_t)rows[e] + (size_t)m_nlp * (size_t)cols[e]] == vals[e]);
+    }
+    printf("sparse_in_range=%ld\nsparse_equals_dense=%ld\n", in_range, agree);
+
+    const int ok = guards_intact(x, (size_t)n_nlp) && guards_intact(lb, (size_t)m_nlp) && guards_intact(ub, (size_t)m_nlp) &&
+                   guards_intact(grad, (size_t)n_nlp) && guards_intact(g, (size_t)m_nlp) && guards_intact(jac, nd) &&
+                   guards_intact(vals, (size_t)nnz);
+    printf("guards_intact=%d\n", ok);
+    QK(qln_destroy(h));
+    return ok ? 0 : 4;
+}

@@ -68,3 +68,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower(), f
+
+
+def test_c_host_program_compiles_and_links_against_the_abi(tmp_path):
+    """tests/host_c/moi_host.c (the Julia binding's call sequence from plain C) builds with gcc -Werror against
+    include/qln_evaluator.h and links libqln_hip.so; it is RUN by the GPU tests (test_gpu_baseline_configs.py)."""
+    from tests.helpers import build_c_host
+
+    exe = build_c_host(tmp_path)
+    assert os.path.exists(exe)

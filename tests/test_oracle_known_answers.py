@@ -94,3 +94,21 @@ def test_two_restatements_agree(nb, golden_dir):
     assert np.array_equal(nb["nlp"].eval_c(Z), NP.eval_c(61, 21, 1, nb["xinit"], nb["xterm"], Z)) or \
         np.max(np.abs(nb["nlp"].eval_c(Z) - NP.eval_c(61, 21, 1, nb["xinit"], nb["xterm"], Z))) <= 1e-15
     assert abs(nb["nlp"].eval_f(Z) - NP.eval_f(61, nb["nlp"].cost, Z)) <= 1e-12 * 116.0
+
+
+def test_KA6_iteration0_objective_at_the_bound_pushed_point(nb):
+    """src/main.ipynb:232: Ipopt's iteration-0 objective 1.8380701e+00.  It is not eval_f(Z0) (= 1.5438468): Ipopt
+    evaluates at Z0 pushed inside the (relaxed) variable bounds of solve() (src/moi.jl:51-67).  Reproducing all eight
+    printed digits pins eval_f at a non-solution point AND the variable bounds incl. quirk Q6: with the bounds on
+    F1y/F2y that the source comment describes, the value is 1.8371626 instead."""
+    from quadruped_landing_amd import nlp as NL
+
+    Z0 = O.notebook_initial_guess(61, 21, nb["xinit"], nb["xterm"], nb["Uref"])
+    assert f"{nb['nlp'].eval_f(Z0):.7e}" == "1.5438468e+00"
+    Zp = NL.ipopt_initial_point(Z0, *NL.variable_bounds(61))
+    assert np.count_nonzero(Zp != Z0) == 120  # 60 time steps sitting on a bound, 60 x1_{k+1} = 0 on the Q6 bound
+    assert f"{nb['nlp'].eval_f(Zp):.7e}" == "1.8380701e+00"
+    assert f"{nb['nlp'].eval_f(NL.ipopt_initial_point(Z0, *NL.variable_bounds_forces(61))):.7e}" == "1.8371626e+00"
+    # the pushed variables do not enter the worst constraint row: inf_pr stays 3.13e-01 (KA5)
+    c = nb["nlp"].eval_c(Zp)
+    assert f"{np.max(np.abs(c[: nb['nlp'].cinds()[5][1]])):.2e}" == "3.13e-01"
