@@ -7,11 +7,13 @@ inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2]
 k_trans=14, FP64 -- "config 3" of BASELINE.md): the HBM-bound regime the metric's roofline half is quoted on;
 configs[1] (B=1024, launch-latency regime) is timed beside it and reported under "other".  The --workload names
 config2/config3/config4 follow BASELINE.md's 1-based table, i.e. configs[1]/[2]/[3].
-Multi-GPU: weak scaling, one process per GPU, the shard is generated locally, no data-path
-collective; one RCCL gather of the per-problem results (objective f, constraint violation) to rank 0
-after the K steps, inside the timed region ("gather f, c (or norms)").  The gather
-of the full constraint vectors (379 MB per rank) is timed once outside the region and reported as
-`gather_c_ms`; Jacobian values stay resident on the GPU that produced them.
+Multi-GPU: weak scaling, one process per GPU (the driver's torch.distributed.run line), the shard is generated
+locally, no data-path collective; one RCCL gather of the per-problem results (objective f, constraint violation) to
+rank 0 after the K steps, inside the timed region ("gather f, c (or norms)"), driven through the C ABI
+(qln_comm_*, include/qln_multi.h) -- torch.distributed (gloo) only carries RCCL's 128-byte id from rank 0 to the
+others.  The gather of the full constraint vectors (379 MB per rank) is timed once outside the region and reported as
+`gather_c_ms`; Jacobian values stay resident on the GPU that produced them.  `--gpus N` WITHOUT a launcher drives all
+N devices from this one process through qln_multi_* (same partitioning, same gather).
 """
 import argparse
 import json
@@ -116,6 +118,33 @@ def cpu_baseline(batch, nlp, budget_s=12.0):
     return one, allc
 
 
+def kernel_build_id():
+    """Hash of the kernel sources the loaded library was built from: measured HBM traffic (profiles/traffic.json) is
+    only quoted for the build it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("qln_kernels.hip", "qln_kernel_common.h", "qln_device.h"):
+        h.update(open(os.path.join(ROOT, "quadruped_landing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """(bytes per launch, note): PMC-measured HBM traffic of the hot kernel for this workload, from the profile of
+    THIS build (bench/profile_round.sh stamps profiles/traffic.json with kernel_build_id()), or (None, why not)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        e = json.load(open(tpath)).get(key)
+    except Exception:
+        e = None
+    if not e:
+        return None, f"no PMC profile of workload '{key}' in profiles/traffic.json (bench/profile_round.sh collects one)"
+    if e.get("build_id") != kernel_build_id():
+        return None, (f"profiles/traffic.json['{key}'] ({e.get('hbm_bytes_per_launch'):.4g} B/launch) was taken on kernel build "
+                      f"{e.get('build_id', 'unstamped')}, this is {kernel_build_id()}: not quoted")
+    return e.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, {e.get('profile', 'profiles/')}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,99 +159,65 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=8,
                     help="1 = the Jacobian buffer is a plain allocation; > 1 = it is placed across two 32-GiB regions of device "
                          "memory at setup (HybridNLP.new_vals_placed), falling back to this many timed candidate allocations")
+    ap.add_argument("--mode", default="auto", choices=["auto", "ranks", "single-process"],
+                    help="how N GPUs are driven: 'ranks' = one process per GPU (a launcher set WORLD_SIZE/RANK/LOCAL_RANK: the "
+                         "driver's torch.distributed.run line), RCCL through qln_comm_*; 'single-process' = this process "
+                         "drives all N devices through qln_multi_* (include/qln_multi.h); auto = ranks under a launcher, "
+                         "else single-process when --gpus > 1")
     args = ap.parse_args()
 
-    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
-    # command line the driver uses) as CHILD processes and relay rank 0's JSON line.  Nothing has touched the GPU
-    # yet in this process, and it never will: it only waits.  Under a launcher (WORLD_SIZE set) the two must agree.
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None and int(env_world) != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
-    if args.gpus > 1 and env_world is None:
-        import socket
-        import subprocess
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}")
+    mode = args.mode
+    if mode == "auto":
+        mode = "ranks" if env_world is not None else ("single-process" if args.gpus > 1 else "ranks")
+    if mode == "single-process" and env_world is not None and int(env_world) > 1:
+        raise SystemExit("bench.py: --mode single-process under a multi-rank launcher")
 
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
-
-    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
-    # fd 1 when the process group is created), so everything that is not the result goes to stderr: fd 1 is pointed at
-    # stderr for the duration of the run and the JSON line is written to the saved descriptor at the end.
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner to fd 1 when a
+    # communicator is created), so everything that is not the result goes to stderr: fd 1 is pointed at stderr for the
+    # duration of the run and the JSON line is written to the saved descriptor at the end.
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
     import torch
-    import torch.distributed as dist
-    from quadruped_landing_amd import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("QLN_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    if mode == "single-process":
+        out = run_single_process(args)
+    else:
+        out = run_ranks(args)
+    if out is not None:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
-    # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
-    batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
-                                   jac_format=args.jac_format)
-    placement_ms = list(build.last_trials)
-    placement_how = build.last_placement
-    f, viol = nlp.new_f(), nlp.new_f()
-    K, W = args.steps, args.warmup
 
-    multi = world > 1 or force_dist
+def base_record(args, value, n_gpus, elapsed, batch_B, batch_N, z_stride, extra_config):
+    return {
+        "metric": "knot-point constraint+Jacobian evals/sec",
+        "value": value,
+        "unit": "knot-evals/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": dict({"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] (0-based; 'config {args.workload[-1]}' of "
+                                    f"BASELINE.md): {WORKLOADS[args.workload]['desc']}; per-GPU shard, constants of the Jacobian "
+                                    "pre-written",
+                         "jac_format": args.jac_format, "problems_per_gpu": batch_B, "knots": batch_N, "z_stride": int(z_stride)},
+                        **extra_config),
+    }
 
-    def barrier():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
 
-    # warmup (untimed): W launches, one objective pass, and one gather so RCCL is initialised
-    nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
-    nlp.eval_f(Z, f)
-    nlp.constraint_violation(c, viol)
-    if multi:
-        D.gather_results(f, viol)
-    barrier()
-
-    t0 = time.perf_counter()
-    ms_each = nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=K)  # K launches, HIP events around each
-    t_gather = 0.0
-    if multi:
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        nlp.eval_f(Z, f)
-        nlp.constraint_violation(c, viol)
-        D.gather_results(f, viol)  # the single end-of-job exchange (RCCL over xGMI): per-problem results
-        torch.cuda.synchronize()
-        t_gather = time.perf_counter() - tg
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
-    t_gather = D.max_over_ranks(t_gather, dev)
-    t_gather_c = 0.0
-    if multi:  # for the record, outside the timed region: the full constraint vectors to rank 0
-        D.gather_to_root(c)
-        barrier()
-        tg = time.perf_counter()
-        D.gather_to_root(c)
-        torch.cuda.synchronize()
-        t_gather_c = D.max_over_ranks(time.perf_counter() - tg, dev)
-
-    knots_per_step = batch.B * batch.N * world
-    value = knots_per_step * K / elapsed
-
+def roofline_record(args, batch, ms_each):
     structural = args.jac_format == "structural"
     # the bytes a launch must move: dense 15x20 blocks or, when only the structural non-zeros are
     # written, 8d's strict figure
@@ -231,43 +226,146 @@ def main():
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     strict = float(np.sum(strict_bytes(batch.N, batch.k_trans)))
     strict_achieved = strict / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(args.workload + ("_structural" if structural else ""), {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_note = measured_traffic(args.workload + ("_structural" if structural else ""))
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_note,
+            "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms, "launch_ms_min": float(np.min(ms_each)),
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N),
+            # the output format is the dense 15x20 block, so the figure that counts only structurally
+            # non-zero entries is quoted beside it
+            "strict_nnz": {"bytes_per_knot_eval": strict / (batch.B * batch.N), "achieved": strict_achieved,
+                           "frac": strict_achieved / HBM_PEAK_GBS}}
 
-    out = {
-        "metric": "knot-point constraint+Jacobian evals/sec",
-        "value": value,
-        "unit": "knot-evals/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] (0-based; 'config {args.workload[-1]}' of BASELINE.md): {WORKLOADS[args.workload]['desc']}; "
-                               "per-rank shard, constants of the Jacobian pre-written",
-                   "jac_format": args.jac_format, "problems_per_gpu": batch.B, "knots": batch.N, "z_stride": int(nlp.z_stride),
-                   "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms},
-    }
+
+def run_single_process(args):
+    """--mode single-process: this process drives all N devices through include/qln_multi.h (one handle, stream and
+    buffer set per device; launches issued to every device before anything is waited for; one RCCL gather of the
+    per-problem objective and constraint violation to device 0 at the end, inside the timed region)."""
+    import torch
+    from quadruped_landing_amd import multi, problem_gen as PG
+
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible")
+    w = WORKLOADS[args.workload]
+    shards = [PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=r, ragged=w["ragged"], build_obj=False) for r in range(n)]
+    cat = lambda name: np.concatenate([getattr(b, name) for b in shards])
+    m = multi.MultiNLP(shards[0].model, None, cat("init_mode"), cat("k_trans"), w["N"], cat("x0"), cat("xf"),
+                       devices=list(range(n)), jac_format=args.jac_format)
+    m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=w["ragged"])
+    m.set_Z(cat("Z"))
+    m.synchronize()
+    m.alloc_vals(placed=args.placement_trials > 1)
+    K, W = args.steps, args.warmup
+    what = multi.GATHER_F | multi.GATHER_VIOL
+    m.time_c_and_jac(0, max(W, 1))  # warm-up launches, and one gather so that RCCL is initialised
+    m.eval_f()
+    m.constraint_violation()
+    m.gather(what)
+    m.synchronize()
+    t0 = time.perf_counter()
+    ms_dev = m.time_c_and_jac(0, K)  # K launches per device, all devices concurrently; returns with the devices idle
+    tg = time.perf_counter()
+    m.eval_f()
+    m.constraint_violation()
+    m.gather(what)                   # the single end-of-job exchange (RCCL over xGMI)
+    m.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    total_B = w["B"] * n
+    out = base_record(args, total_B * w["N"] * K / elapsed, n, elapsed, w["B"], w["N"], m.z_stride,
+                      {"driver": "one process, qln_multi_* (include/qln_multi.h)",
+                       "jacobian_buffer": "qln_vals_alloc_placed per device" if args.placement_trials > 1 else "plain allocation"})
+    out["roofline"] = roofline_record(args, shards[0], ms_dev[:1] / K)
+    out["roofline"]["launch_ms_avg_per_device"] = [float(x) / K for x in ms_dev]
+    out["gather_ms"] = (t1 - tg) * 1e3
+    f, viol, _ = m.gathered()
+    assert f.shape == (total_B,) and np.all(np.isfinite(f)) and np.all(np.isfinite(viol))
+    m.close()
+    return out
+
+
+def run_ranks(args):
+    """One process per GPU.  Under a launcher (the driver's `python -m torch.distributed.run --nproc-per-node N ...`)
+    every rank builds its shard locally and evaluates it with its own handle; there is no data-path collective.  RCCL
+    is driven through the C ABI (qln_comm_*, include/qln_multi.h): rank 0's 128-byte id reaches the others over a gloo
+    (TCP) rendezvous, which is all torch.distributed is used for."""
+    import torch
+    import torch.distributed as dist
+    from quadruped_landing_amd import multi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    force_dist = os.environ.get("QLN_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
+    multi_rank = world > 1 or force_dist
+    comm = None
+    if multi_rank:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        uid = [multi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = multi.Comm(uid[0], rank, world, local_rank)
+
+    # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
+    batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
+                                   jac_format=args.jac_format)
+    placement_ms = list(build.last_trials)
+    placement_how = build.last_placement
+    f, viol = nlp.new_f(), nlp.new_f()
+    K, W = args.steps, args.warmup
+    structural = args.jac_format == "structural"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+
+    # warmup (untimed): W launches, one objective pass, and one gather so RCCL's channels exist
+    nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
+    nlp.eval_f(Z, f)
+    nlp.constraint_violation(c, viol)
+    if comm is not None:
+        comm.gather(f)
+        comm.gather(viol)
+    barrier()
+
+    t0 = time.perf_counter()
+    ms_each = nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=K)  # K launches, HIP events around each
+    t_gather = 0.0
+    if comm is not None:
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        nlp.eval_f(Z, f)
+        nlp.constraint_violation(c, viol)
+        f_all, _ = comm.gather(f)        # the single end-of-job exchange (RCCL over xGMI): per-problem results
+        viol_all, _ = comm.gather(viol)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+        t_gather = comm.max(t_gather)
+    t_gather_c = 0.0
+    if comm is not None:  # for the record, outside the timed region: the full (ragged) constraint vectors to rank 0
+        comm.gather(c)
+        barrier()
+        tg = time.perf_counter()
+        comm.gather(c)
+        torch.cuda.synchronize()
+        t_gather_c = comm.max(time.perf_counter() - tg)
+
+    out = None
     if rank == 0:
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms,
-                           "launch_ms_min": float(np.min(ms_each)), "algorithmic_bytes_per_launch": alg_bytes,
-                           "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N),
-                           # the output format is the dense 15x20 block, so the figure that counts only
-                           # structurally non-zero entries is quoted beside it
-                           "strict_nnz": {"bytes_per_knot_eval": strict / (batch.B * batch.N), "achieved": strict_achieved,
-                                          "frac": strict_achieved / HBM_PEAK_GBS}}
-        if multi:
+        out = base_record(args, batch.B * batch.N * world * K / elapsed, world, elapsed, batch.B, batch.N, nlp.z_stride,
+                          {"driver": "one process per GPU" + (", RCCL through qln_comm_* (include/qln_multi.h)" if comm is not None else ""),
+                           "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms})
+        out["roofline"] = roofline_record(args, batch, ms_each)
+        if comm is not None:
+            assert f_all.numel() == batch.B * world and viol_all.numel() == batch.B * world
             out["gather_ms"] = t_gather * 1e3        # f + constraint violation, inside the timed region
             out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank), outside it
         if world == 1 and not args.no_other and not structural:
@@ -298,11 +396,11 @@ def main():
             one, allc = cpu_baseline(batch, nlp)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if multi:
-        dist.barrier()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

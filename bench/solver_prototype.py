@@ -1,0 +1,268 @@
+"""CPU prototype (numpy + the oracle's dynamics) of the batched solver that qln_solver_kernels.hip implements on the
+GPU: augmented-Lagrangian iLQR ("Riccati sweep per problem") for the reference NLP of src/moi.jl:46-103.
+
+Development aid only -- run here to choose the algorithm and its constants before writing kernels; not imported by the
+product, not a test.  The dynamics / Jacobians come from the oracle (test infrastructure).
+
+  python bench/solver_prototype.py [notebook|random N kt seed] [reference|exact]
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import oracle as O  # noqa: E402
+
+JUMP_KEEP = np.array([1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 1.0])  # true derivative of the jump map (clock kept)
+
+
+class Problem:
+    def __init__(self, N, kt, im, x0, xf, cost, model=None):
+        self.N, self.kt, self.im = N, kt, im
+        self.x0, self.xf, self.cost = x0.copy(), xf.copy(), cost
+        self.m = model or O.default_model()
+        self.lb = self.m.lb
+        self.h_lo, self.h_hi = 0.001, 0.02
+
+    def mode(self, k):  # 0-based dynamics knot k, K = k + 1
+        K = k + 1
+        return (self.im if K <= self.kt - 1 else 3), (K == self.kt - 1)
+
+    def step(self, k, x, u):
+        mode, jump = self.mode(k)
+        xn = O.contact_dynamics_rk4(mode, x, u, self.m)
+        if jump:
+            xn[4] = xn[6] = 0.0
+            xn[10:14] = 0.0
+        return xn
+
+    def step_jac(self, k, x, u):
+        mode, jump = self.mode(k)
+        J = O.contact_jacobian(mode, x, u, self.m)
+        if jump:
+            J = JUMP_KEEP[:, None] * J
+        return J[:, :15], J[:, 15:]
+
+
+def rollout(p, x0, U):
+    X = np.zeros((p.N, 15))
+    X[0] = x0
+    for k in range(p.N - 1):
+        X[k + 1] = p.step(k, X[k], U[k])
+    return X
+
+
+def stage_terms(p, k, x, u, lam, rho, w):
+    """Value, gradient, GN Hessian of the AL stage cost at knot k (0-based; k == N-1 is the terminal knot, u = None).
+    w = weight on the stage cost (h_k or the frozen h_k); returns also constraint violation of the knot."""
+    N = p.N
+    rec = p.cost[k]
+    nz = 20 if k < N - 1 else 15
+    z = np.concatenate([x, u]) if k < N - 1 else x
+    D, d, c0 = rec[:nz] if nz == 20 else rec[:15], (rec[20:40] if nz == 20 else rec[20:35]), rec[40]
+    ell = 0.5 * np.sum(D * z * z) + np.sum(d * z) + c0
+    g = w * (D * z + d)
+    H = np.diag(w * D)
+    val = w * ell
+    viol = 0.0
+    # --- equality constraints of this knot
+    eq = []  # (value, gradient)
+    if k == N - 1:
+        for i in range(14):
+            e = np.zeros(nz)
+            e[i] = 1.0
+            eq.append((x[i] - p.xf[i], e))
+    if k == N - 2:
+        e = np.zeros(nz)
+        e[16] = e[18] = 1.0
+        eq.append((u[1] + u[3] + p.m.mb * p.m.g, e))
+    for j, (ev, eg) in enumerate(eq):
+        l = lam["eq"][k][j]
+        val += l * ev + 0.5 * rho * ev * ev
+        g = g + (l + rho * ev) * eg
+        H = H + rho * np.outer(eg, eg)
+        viol = max(viol, abs(ev))
+    # --- inequalities  gi(x) <= 0
+    ineq = []
+    s, cth = np.sin(x[2]), np.cos(x[2])
+    gcl = np.zeros(nz)
+    gcl[1] = -1.0
+    gcl[2] = (p.lb / 2) * cth * (1.0 if s > 0 else -1.0)
+    ineq.append((-(x[1] - (p.lb / 2) * abs(s)), gcl))                      # clearance >= 0
+    e = np.zeros(nz); e[2] = 1.0
+    ineq.append((x[2] - np.pi / 2, e.copy()))                              # theta <= pi/2
+    ineq.append((-x[2] - np.pi / 2, -e))                                   # theta >= -pi/2
+    if k >= 1:                                                             # Q6: yb_{k+1} >= 0, x1_{k+1} >= 0 (src/moi.jl:64-65)
+        e = np.zeros(nz); e[1] = -1.0
+        ineq.append((-x[1], e))
+        e = np.zeros(nz); e[3] = -1.0
+        ineq.append((-x[3], e))
+    for j, (gv, gg) in enumerate(ineq):
+        l = lam["in"][k][j]
+        t = l + rho * gv
+        if t > 0:
+            val += (t * t - l * l) / (2 * rho)
+            g = g + t * gg
+            H = H + rho * np.outer(gg, gg)
+        else:
+            val += -l * l / (2 * rho)
+        viol = max(viol, gv)
+    return val, g, H, viol, [e[0] for e in eq], [i[0] for i in ineq]
+
+
+def total_cost(p, X, U, lam, rho, W):
+    J, viol = 0.0, 0.0
+    for k in range(p.N):
+        w = W[k] if k < p.N - 1 else 1.0
+        v, _, _, vi, _, _ = stage_terms(p, k, X[k], U[k] if k < p.N - 1 else None, lam, rho, w)
+        J += v
+        viol = max(viol, vi)
+    return J, viol
+
+
+def ilqr_iteration(p, X, U, lam, rho, mu, exact_h):
+    N = p.N
+    W = U[:, 4].copy()  # stage weights h_k (frozen during the iteration in reference-gradient mode)
+    # backward pass
+    P = None
+    Ks, ds = [None] * (N - 1), [None] * (N - 1)
+    v, gN, HN, _, _, _ = stage_terms(p, N - 1, X[N - 1], None, lam, rho, 1.0)
+    Pm, pv = HN, gN
+    dV1 = dV2 = 0.0
+    for k in range(N - 2, -1, -1):
+        A, B = p.step_jac(k, X[k], U[k])
+        _, g, H, _, _, _ = stage_terms(p, k, X[k], U[k], lam, rho, W[k])
+        if exact_h:
+            # d(h l)/dh = l and the cross terms d2(h l)/dh d(x,u) = grad l
+            rec = p.cost[k]
+            z = np.concatenate([X[k], U[k]])
+            ell = 0.5 * np.sum(rec[:20] * z * z) + np.sum(rec[20:40] * z) + rec[40]
+            gl = rec[:20] * z + rec[20:40]
+            g = g.copy(); g[19] += ell
+            H = H.copy(); H[19, :] += gl; H[:, 19] += gl
+        Qx = g[:15] + A.T @ pv
+        Qu = g[15:] + B.T @ pv
+        Qxx = H[:15, :15] + A.T @ Pm @ A
+        Quu = H[15:, 15:] + B.T @ Pm @ B + mu * np.eye(5)
+        Qux = H[15:, :15] + B.T @ Pm @ A
+        # box on h (control 4): clamp the feed-forward, zero the gain row if clamped
+        lo, hi = p.h_lo - U[k, 4], p.h_hi - U[k, 4]
+        try:
+            L = np.linalg.cholesky(Quu)
+        except np.linalg.LinAlgError:
+            return None
+        dff = -np.linalg.solve(Quu, Qu)
+        K = -np.linalg.solve(Quu, Qux)
+        if dff[4] < lo or dff[4] > hi:
+            hclamp = min(max(dff[4], lo), hi)
+            f = [0, 1, 2, 3]
+            Qf = Quu[np.ix_(f, f)]
+            rhs = Qu[f] + Quu[f, 4] * hclamp
+            dff = np.zeros(5); dff[4] = hclamp
+            dff[f] = -np.linalg.solve(Qf, rhs)
+            K = np.zeros((5, 15))
+            K[f] = -np.linalg.solve(Qf, Qux[f])
+        Ks[k], ds[k] = K, dff
+        dV1 += dff @ Qu
+        dV2 += 0.5 * dff @ Quu @ dff
+        pv = Qx + K.T @ Quu @ dff + K.T @ Qu + Qux.T @ dff
+        Pm = Qxx + K.T @ Quu @ K + K.T @ Qux + Qux.T @ K
+        Pm = 0.5 * (Pm + Pm.T)
+    # forward pass with line search on the AL cost (weights frozen at W in reference mode)
+    J0, _ = total_cost(p, X, U, lam, rho, W if not exact_h else U[:, 4])
+    for alpha in [1.0, 0.5, 0.25, 0.125, 0.0625, 0.03, 0.01, 0.003]:
+        Xn, Un = np.zeros_like(X), np.zeros_like(U)
+        Xn[0] = X[0]
+        for k in range(N - 1):
+            Un[k] = U[k] + alpha * ds[k] + Ks[k] @ (Xn[k] - X[k])
+            Un[k, 4] = min(max(Un[k, 4], p.h_lo), p.h_hi)
+            Xn[k + 1] = p.step(k, Xn[k], Un[k])
+        Jn, _ = total_cost(p, Xn, Un, lam, rho, W if not exact_h else Un[:, 4])
+        exp = -(alpha * dV1 + alpha * alpha * dV2)
+        if np.isfinite(Jn) and J0 - Jn >= 1e-4 * max(exp, 0.0) and Jn < J0:
+            return Xn, Un, J0, Jn, alpha
+    return False
+
+
+def solve(p, U0, exact_h=False, outer=30, inner=60, verbose=True):
+    N = p.N
+    U = U0.copy()
+    U[:, 4] = np.clip(U[:, 4], p.h_lo, p.h_hi)
+    X = rollout(p, p.x0, U)
+    lam = {"eq": [np.zeros(15) for _ in range(N)], "in": [np.zeros(5) for _ in range(N)]}
+    rho, mu = 1.0, 1e-6
+    t0 = time.time()
+    iters = 0
+    prev_viol = np.inf
+    for o in range(outer):
+        for it in range(inner):
+            r = ilqr_iteration(p, X, U, lam, rho, mu, exact_h)
+            iters += 1
+            if r is None or r is False:
+                mu = min(mu * 10, 1e6)
+                if mu >= 1e6:
+                    break
+                continue
+            X, U, J0, Jn, alpha = r
+            mu = max(mu / 3, 1e-8)
+            if J0 - Jn < 1e-7 * (1 + abs(Jn)):
+                break
+        W = U[:, 4]
+        J, viol = total_cost(p, X, U, lam, rho, W)
+        # multiplier update
+        for k in range(N):
+            _, _, _, _, eqv, inv = stage_terms(p, k, X[k], U[k] if k < N - 1 else None, lam, rho, 1.0)
+            for j, e in enumerate(eqv):
+                lam["eq"][k][j] += rho * e
+            for j, gv in enumerate(inv):
+                lam["in"][k][j] = max(0.0, lam["in"][k][j] + rho * gv)
+        f = sum(U[k, 4] * stagecost(p, k, X[k], U[k]) for k in range(N - 1)) + stagecost(p, N - 1, X[N - 1], None)
+        if verbose:
+            print(f"outer {o:2d} rho {rho:8.1e} iters {iters:4d} f {f:12.6f} viol {viol:9.3e} mu {mu:7.1e} sum h {U[:,4].sum():.4f} t {time.time()-t0:5.1f}s")
+        if viol < 1e-7:
+            break
+        if viol > 0.25 * prev_viol:
+            rho = min(rho * 10, 1e8)
+        prev_viol = viol
+    return X, U, f, viol, iters
+
+
+def stagecost(p, k, x, u):
+    rec = p.cost[k]
+    z = np.concatenate([x, u]) if u is not None else x
+    n = z.size
+    return 0.5 * np.sum(rec[:n] * z * z) + np.sum(rec[20 : 20 + n] * z) + rec[40]
+
+
+def pack(X, U):
+    N = X.shape[0]
+    Z = np.zeros(20 * N - 5)
+    Z[: 20 * (N - 1)] = np.concatenate([X[:-1], U], axis=1).reshape(-1)
+    Z[20 * (N - 1) :] = X[-1]
+    return Z
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "notebook"
+    if which == "notebook":
+        nlp, xinit, xterm, Xref, Uref = O.notebook_problem()
+        p = Problem(61, 21, 1, xinit, xterm, nlp.cost)
+        U0 = Uref.copy()
+        mode_arg = sys.argv[2] if len(sys.argv) > 2 else "reference"
+    else:
+        from quadruped_landing_amd import problem_gen as PG
+        N, kt, seed = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        b = PG.make_batch(4, N, kt, 1, seed=seed)
+        nlp = O.OracleNLP(N, kt, 1, b.x0[0], b.xf[0], b.obj)
+        p = Problem(N, kt, 1, b.x0[0], b.xf[0], b.obj)
+        from quadruped_landing_amd.ref_traj import reference_trajectory
+        _, Ur = reference_trajectory(b.model, N, b.k_trans[:1], b.xf[:1], b.init_mode[:1], 0.009)
+        U0 = Ur[0]
+        mode_arg = sys.argv[5] if len(sys.argv) > 5 else "reference"
+    X, U, f, viol, iters = solve(p, U0, exact_h=(mode_arg == "exact"))
+    Z = pack(X, U)
+    c = nlp.eval_c(Z)
+    neq = nlp.cinds()[5][1]
+    print("oracle: f =", nlp.eval_f(Z), " max|c_eq| =", np.max(np.abs(c[:neq])), " min clearance =", c[neq:].min(), " iters", iters)
+    print("h:", np.round(U[:, 4], 4))

@@ -115,6 +115,8 @@ typedef struct qln_dims {
 } qln_dims;
 
 const char* qln_last_error(void);        /* thread-local message of the last failing call */
+/* for the companion libraries of this ABI (qln_multi.h): records `msg` in the same slot and returns `code` */
+int qln_set_last_error(int code, const char* msg);
 const char* qln_version(void);
 
 /* Lifetime.  `device` is a HIP device ordinal. */

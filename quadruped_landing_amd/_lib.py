@@ -74,6 +74,7 @@ _vp, _dp = C.c_void_p, C.c_void_p  # device or host double* passed as raw addres
 _i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 SIGNATURES = {
     "qln_last_error": (C.c_char_p, []),
+    "qln_set_last_error": (C.c_int, [C.c_int, C.c_char_p]),
     "qln_version": (C.c_char_p, []),
     "qln_create": (C.c_int, [C.POINTER(QlnBatchDesc), C.c_int, C.POINTER(_vp)]),
     "qln_destroy": (C.c_int, [_vp]),

@@ -162,6 +162,7 @@ int bind_device(const qln_handle* h) {
 extern "C" {
 
 const char* qln_last_error(void) { return g_err.c_str(); }
+int qln_set_last_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 const char* qln_version(void) { return "quadruped_landing_amd 0.1 (gfx950)"; }
 
 int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {

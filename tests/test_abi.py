@@ -77,3 +77,41 @@ def test_c_host_program_compiles_and_links_against_the_abi(tmp_path):
 
     exe = build_c_host(tmp_path)
     assert os.path.exists(exe)
+
+
+def _declared_in(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qln_[A-Za-z_]+)\s*\(", src)))
+
+
+def test_multi_gpu_header_binding_and_library_agree():
+    """include/qln_multi.h <-> quadruped_landing_amd/multi.py <-> libqln_multi.so (loads without a GPU)."""
+    from quadruped_landing_amd import multi
+
+    assert _declared_in("qln_multi.h") == sorted(multi.SIGNATURES)
+    L = multi.lib()
+    for name in multi.SIGNATURES:
+        assert hasattr(L, name), name
+
+
+def test_the_c_and_python_partitioning_rules_are_the_same():
+    from quadruped_landing_amd import distributed as D, multi
+
+    for n in (1, 7, 11, 64, 65536, 524288, 524289):
+        for w in (1, 2, 3, 8):
+            if n >= w:
+                assert [multi.shard_range(n, r, w) for r in range(w)] == [D.shard_range(n, r, w) for r in range(w)]
+
+
+def test_multi_create_without_a_gpu_fails_loudly():
+    import numpy as np
+    from quadruped_landing_amd import multi, problem_gen as PG
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    b = PG.make_batch(4, 8, 3, 1, seed=0)
+    with pytest.raises(_lib.QlnError) as e:
+        multi.MultiNLP(b.model, b.obj, b.init_mode, b.k_trans, b.N, b.x0, b.xf, devices=[0])
+    assert e.value.code == _lib.QLN_ERR_NO_DEVICE

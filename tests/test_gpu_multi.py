@@ -1,0 +1,87 @@
+"""include/qln_multi.h on the GPU box: the multi-GPU layer with however many devices are visible (the pool gives one,
+so the degenerate one-shard clique -- which still goes through ncclCommInitAll / ncclCommInitRank, ncclSend / ncclRecv
+inside a group, ncclAllGather, ncclAllReduce).  Shard -> handle -> evaluate -> gather must give exactly what one
+single-GPU handle over the whole batch gives."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(batch):
+    import torch
+    from quadruped_landing_amd import HybridNLP
+
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z = nlp.upload_Z(batch.Z)
+    c, v = nlp.eval_c_and_jac(Z, write_constants=True)
+    f, viol = nlp.eval_f(Z), nlp.constraint_violation(c)
+    torch.cuda.synchronize()
+    return nlp, c.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy(), viol.cpu().numpy()
+
+
+@pytest.mark.parametrize("ragged,placed", [(False, False), (True, False), (True, True)])
+def test_single_process_multi_device_path_equals_the_single_handle(ragged, placed):
+    import ctypes as C
+    import torch
+    from quadruped_landing_amd import _lib, multi, problem_gen as PG
+
+    ndev = torch.cuda.device_count()
+    batch = PG.make_batch(37, 25, 9, 1, seed=12, ragged=ragged)
+    nlp, c1, v1, f1, viol1 = _single(batch)
+    m = multi.MultiNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                       devices=list(range(ndev)))
+    m.set_Z(batch.Z)
+    m.alloc_vals(placed=placed)
+    m.eval_c_and_jac(with_jacobian=True, write_constants=True)
+    m.eval_f()
+    m.constraint_violation()
+    m.gather(multi.GATHER_F | multi.GATHER_VIOL | multi.GATHER_C)  # stream-ordered behind the evaluations
+    f, viol, c = m.gathered(c=True)
+    assert np.array_equal(f, f1) and np.array_equal(viol, viol1)
+    # the gathered constraint vector: problem b at c_off[b]; with one shard the layout is the single handle's
+    for b in range(batch.B):
+        mm = nlp.problem_dims(b)[0]
+        assert np.array_equal(c[m.c_off[b] : m.c_off[b] + mm], nlp.split_c(c1, b)), b
+    # shards tile the batch and their Jacobian buffers hold what the single handle computes for those problems
+    end = 0
+    for r in range(m.n_devices):
+        s = m.shard(r)
+        assert s["begin"] == end
+        end = s["end"]
+        dims = _lib.QlnDims()
+        _lib.check(_lib.lib().qln_get_dims(s["handle"], C.byref(dims)))
+        nb = s["end"] - s["begin"]
+        j_off = np.zeros(nb, dtype=np.int64)
+        _lib.check(_lib.lib().qln_get_offsets(s["handle"], None, j_off.ctypes.data_as(C.POINTER(C.c_int64))))
+        m.synchronize()
+        vals = m.shard_tensor(r, "vals").cpu().numpy()
+        assert vals.size == dims.j_total
+        for i in range(nb):
+            b = s["begin"] + i
+            nz = nlp.problem_dims(b)[1]
+            assert np.array_equal(vals[j_off[i] : j_off[i] + nz], nlp.split_vals(v1, b)), b
+    assert end == batch.B
+    ms = m.time_c_and_jac(1, 3)
+    assert ms.shape == (m.n_devices,) and np.all(ms > 0)
+    m.close()
+
+
+def test_one_process_per_gpu_communicator_with_the_ranks_that_fit_on_this_box():
+    """qln_comm_*: world = 1 on a one-GPU box (RCCL refuses two ranks on one device).  The id / init / count exchange
+    / grouped send+recv / max / barrier sequence is the one bench.py runs under torch.distributed.run."""
+    import torch
+    from quadruped_landing_amd import multi
+
+    uid = multi.Comm.unique_id()
+    assert len(uid) == 128
+    comm = multi.Comm(uid, 0, 1, 0)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+    out, counts = comm.gather(t)
+    torch.cuda.synchronize()
+    assert counts == [1000] and torch.equal(out, t)
+    out, counts = comm.gather(t[:0])  # an empty shard is legal
+    assert counts == [0] and out.numel() == 0
+    assert comm.max(3.25) == 3.25
+    comm.barrier()
+    comm.close()
