@@ -140,7 +140,7 @@ def ilqr_iteration(p, X, U, lam, rho, mu, exact_h):
             ell = 0.5 * np.sum(rec[:20] * z * z) + np.sum(rec[20:40] * z) + rec[40]
             gl = rec[:20] * z + rec[20:40]
             g = g.copy(); g[19] += ell
-            H = H.copy(); H[19, :] += gl; H[:, 19] += gl
+            pass  # GN: the indefinite cross terms d2(h l)/dh d(x,u) are left out
         Qx = g[:15] + A.T @ pv
         Qu = g[15:] + B.T @ pv
         Qxx = H[:15, :15] + A.T @ Pm @ A
@@ -196,6 +196,7 @@ def solve(p, U0, exact_h=False, outer=30, inner=60, verbose=True):
     iters = 0
     prev_viol = np.inf
     for o in range(outer):
+        mu = 1e-6
         for it in range(inner):
             r = ilqr_iteration(p, X, U, lam, rho, mu, exact_h)
             iters += 1
@@ -220,7 +221,7 @@ def solve(p, U0, exact_h=False, outer=30, inner=60, verbose=True):
         f = sum(U[k, 4] * stagecost(p, k, X[k], U[k]) for k in range(N - 1)) + stagecost(p, N - 1, X[N - 1], None)
         if verbose:
             print(f"outer {o:2d} rho {rho:8.1e} iters {iters:4d} f {f:12.6f} viol {viol:9.3e} mu {mu:7.1e} sum h {U[:,4].sum():.4f} t {time.time()-t0:5.1f}s")
-        if viol < 1e-7:
+        if viol < 1e-6:
             break
         if viol > 0.25 * prev_viol:
             rho = min(rho * 10, 1e8)
@@ -253,9 +254,11 @@ if __name__ == "__main__":
     else:
         from quadruped_landing_amd import problem_gen as PG
         N, kt, seed = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-        b = PG.make_batch(4, N, kt, 1, seed=seed)
-        nlp = O.OracleNLP(N, kt, 1, b.x0[0], b.xf[0], b.obj)
-        p = Problem(N, kt, 1, b.x0[0], b.xf[0], b.obj)
+        idx = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+        Bn = int(sys.argv[7]) if len(sys.argv) > 7 else 4
+        b = PG.make_batch(Bn, N, kt, 1, seed=seed, noise=0.0)
+        nlp = O.OracleNLP(N, kt, 1, b.x0[idx], b.xf[idx], b.obj)
+        p = Problem(N, kt, 1, b.x0[idx], b.xf[idx], b.obj)
         from quadruped_landing_amd.ref_traj import reference_trajectory
         _, Ur = reference_trajectory(b.model, N, b.k_trans[:1], b.xf[:1], b.init_mode[:1], 0.009)
         U0 = Ur[0]

@@ -171,6 +171,41 @@ int qln_eval_constraint_vjp(qln_handle* h, const double* Z, const double* lam, d
 int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, double* dZ, int32_t max_iters, double rel_tol,
                           const double* radius /*[B] or NULL*/, const double* col_scale /*[n_nlp] or NULL*/,
                           double* info /*[B][QLN_GN_INFO_STRIDE] or NULL*/);
+/* Batched solve of the reference NLP on the GPU -- the caller of this evaluator in the reference, solve() of
+ * src/moi.jl:46-103 (objective eval_f, constraints eval_c! with the bounds of src/nlp.jl:66-69, the variable bounds
+ * of src/moi.jl:51-67 incl. quirk Q6), for every problem of the batch at once, one wavefront per problem.
+ * Method (quadruped_landing_amd/csrc/qln_ilqr_kernels.hip): augmented-Lagrangian iLQR -- the states are eliminated by
+ * rolling the controls out from x0 with the evaluator's own RK4 step, a Newton-type step is a Riccati sweep over the
+ * knots in LDS (the step blocks are the evaluator's closed form), terminal / final-control rows, clearance rows and
+ * the state bounds carry multipliers + penalty, the bounds on the step length h are kept inside the sweep.
+ * Z (device, layout of Z): in = initial guess, of which the CONTROLS u_k are used (h clamped to its bounds; the
+ * states are rolled out from x0); out = the solution: its dynamics / initial-condition rows are zero to the last bit
+ * by construction, the remaining rows to options->tol_violation when status = 0.
+ * info (device, may be NULL): QLN_SOLVE_INFO_STRIDE doubles per problem {outer iterations, iLQR iterations, objective
+ * f of the returned Z, constraint violation (the solver's measure: the rows and bounds it penalises), final penalty
+ * rho, status (0 = converged to tol_violation, 1 = iteration limit, 2 = no descent at the largest penalty),
+ * augmented cost, last accepted step length, sum of h, LM mu at exit, 0...}.
+ * There is no reference oracle for the iterates (the reference hands its callbacks to Ipopt); the result is judged by
+ * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
+ * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~140).  Stream-ordered. */
+typedef struct qln_solve_options {
+    int32_t max_outer;        /* multiplier updates                                   default 30   */
+    int32_t max_inner;        /* iLQR iterations per multiplier update                default 60   */
+    double tol_violation;     /* stop when the violation is <= this                   default 1e-6 (solve()'s c_tol) */
+    double inner_tol;         /* inner loop ends when the cost decrease is below inner_tol (1 + |J|)   default 1e-7 */
+    double rho0, rho_factor, rho_max;  /* penalty schedule                            default 1, 10, 1e8 */
+    double h_min, h_max;      /* bounds on the step length (src/moi.jl:58-61)         default 0.001, 0.02 */
+    double theta_min, theta_max;       /* bounds on the body angle (src/moi.jl:54-56) default -pi/2, pi/2 */
+    int32_t q6_bounds;        /* the lower bounds of quirk Q6 (yb_{k+1}, x1_{k+1} >= 0, src/moi.jl:64-65)  default 1 */
+    int32_t exact_h_gradient; /* 0: objective gradient as the reference's grad_f!, which has no d(h l)/dh (quirk Q2) --
+                                 the stage weights h_k are frozen within an iteration; 1: the exact gradient  default 0 */
+    double h_prox;            /* proximal weight on the step lengths in the Newton system (it vanishes at a fixed point):
+                                 with the reference's gradient the objective does not see h, the h_k are fixed by the
+                                 constraints alone and wander along flat directions without it          default 1e4 */
+} qln_solve_options;
+#define QLN_SOLVE_INFO_STRIDE 16
+int qln_solve_default_options(qln_solve_options* opt);
+int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt /* NULL = defaults */, double* info);
 /* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
  * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
  * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */

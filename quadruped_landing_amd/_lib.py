@@ -61,6 +61,28 @@ class QlnDims(C.Structure):
     ]
 
 
+class QlnSolveOptions(C.Structure):
+    _fields_ = [
+        ("max_outer", C.c_int32),
+        ("max_inner", C.c_int32),
+        ("tol_violation", C.c_double),
+        ("inner_tol", C.c_double),
+        ("rho0", C.c_double),
+        ("rho_factor", C.c_double),
+        ("rho_max", C.c_double),
+        ("h_min", C.c_double),
+        ("h_max", C.c_double),
+        ("theta_min", C.c_double),
+        ("theta_max", C.c_double),
+        ("q6_bounds", C.c_int32),
+        ("exact_h_gradient", C.c_int32),
+        ("h_prox", C.c_double),
+    ]
+
+
+SOLVE_INFO_STRIDE = 16
+
+
 class QlnError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"qln error {code}: {msg}")
@@ -97,6 +119,8 @@ SIGNATURES = {
     "qln_eval_constraint_vjp": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_gauss_newton_step": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
+    "qln_solve_default_options": (C.c_int, [C.POINTER(QlnSolveOptions)]),
+    "qln_solve": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
     "qln_set_lqr_cost": (C.c_int, [_vp, _dp, _dp, _dp, C.c_double, C.c_int]),
     "qln_get_cost": (C.c_int, [_vp, _dp, _i32p]),

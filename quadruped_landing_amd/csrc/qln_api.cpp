@@ -113,6 +113,9 @@ struct qln_handle {
         double* vals = nullptr;
     };
     std::vector<Placed> placed;
+    // scratch of qln_solve (step blocks of every knot), allocated on first use
+    double* solve_scratch = nullptr;
+    size_t solve_scratch_n = 0;
 };
 
 namespace {
@@ -310,7 +313,7 @@ int qln_destroy(qln_handle* h) {
     }
     for (qln_handle::Mapped* m : {&h->m_Z, &h->m_c, &h->m_vals, &h->m_f, &h->m_grad})
         if (m->host) (void)hipHostFree(m->host);
-    void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad};
+    void* bufs[] = {h->d_desc, h->d_bnd, h->d_cost, h->s_Z, h->s_c, h->s_vals, h->s_f, h->s_grad, h->solve_scratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete h;
@@ -561,6 +564,72 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
                                              " does not fit one problem in the 160 KB of LDS of a CU (N <= 149)");
     if (int rc = bind_device(h)) return rc;
     QLN_HIP(qln::launch_gauss_newton_step(h->p, Z, c, dZ, max_iters, rel_tol, radius, col_scale, info, h->stream));
+    return QLN_OK;
+}
+
+int qln_solve_default_options(qln_solve_options* o) {
+    if (!o) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_solve_default_options: null");
+    o->max_outer = 30;
+    o->max_inner = 60;
+    o->tol_violation = 1e-6;
+    o->inner_tol = 1e-7;
+    o->rho0 = 1.0;
+    o->rho_factor = 10.0;
+    o->rho_max = 1e8;
+    o->h_min = 0.001;   // src/moi.jl:59-60
+    o->h_max = 0.02;
+    o->theta_min = -M_PI / 2;  // src/moi.jl:55-56
+    o->theta_max = M_PI / 2;
+    o->q6_bounds = 1;
+    o->exact_h_gradient = 0;
+    o->h_prox = 1e4;
+    return QLN_OK;
+}
+
+int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt, double* info) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
+    if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_solve: null Z");
+    qln_solve_options o;
+    qln_solve_default_options(&o);
+    if (opt) o = *opt;
+    if (o.max_outer < 0 || o.max_inner < 1 || !(o.tol_violation > 0) || !(o.rho0 > 0) || !(o.rho_factor > 1) || !(o.rho_max >= o.rho0) ||
+        !(o.h_min > 0) || !(o.h_max >= o.h_min) || !(o.theta_max > o.theta_min) || !(o.inner_tol >= 0) ||
+        !(o.h_prox >= 0))
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_solve: bad options");
+    if (qln::ilqr_lds_bytes(h->dims.N) > 160 * 1024)
+        return fail(QLN_ERR_UNSUPPORTED, "qln_solve: N = " + std::to_string(h->dims.N) + " does not fit one problem in the 160 KB of LDS of a CU");
+    if (int rc = bind_device(h)) return rc;
+    const size_t need = qln::ilqr_scratch_doubles(h->dims.B, h->dims.N);
+    if (h->solve_scratch_n < need) {
+        if (h->solve_scratch) {
+            QLN_HIP(hipStreamSynchronize(h->stream));
+            QLN_HIP(hipFree(h->solve_scratch));
+            h->solve_scratch = nullptr;
+            h->solve_scratch_n = 0;
+        }
+        QLN_HIP(hipMalloc(reinterpret_cast<void**>(&h->solve_scratch), need * sizeof(double)));
+        h->solve_scratch_n = need;
+    }
+    qln::SolveParams sp;
+    sp.max_outer = o.max_outer;
+    sp.max_inner = o.max_inner;
+    sp.tol = o.tol_violation;
+    sp.inner_tol = o.inner_tol;
+    sp.rho0 = o.rho0;
+    sp.rho_factor = o.rho_factor;
+    sp.rho_max = o.rho_max;
+    sp.mu0 = 1e-6;
+    sp.mu_min = 1e-8;
+    sp.mu_max = 1e6;
+    sp.h_lo = o.h_min;
+    sp.h_hi = o.h_max;
+    sp.th_lo = o.theta_min;
+    sp.th_hi = o.theta_max;
+    sp.h_prox = o.h_prox;
+    sp.q6 = o.q6_bounds;
+    sp.exact_h = o.exact_h_gradient;
+    QLN_HIP(qln::launch_al_ilqr(h->p, sp, Z, info, h->solve_scratch, h->stream));
     return QLN_OK;
 }
 

@@ -139,6 +139,21 @@ size_t gauss_newton_lds_bytes(int32_t N);
 hipError_t launch_gauss_newton_step(const BatchParams& p, const double* Z, const double* c, double* dZ, int max_iters,
                                     double rel_tol, const double* radius, const double* col_scale, double* info,
                                     hipStream_t stream);
+// batched augmented-Lagrangian iLQR solve of the reference NLP (qln_ilqr_kernels.hip)
+struct SolveParams {
+    int32_t max_outer, max_inner;
+    double tol, inner_tol;
+    double rho0, rho_factor, rho_max;
+    double mu0, mu_min, mu_max;
+    double h_lo, h_hi, th_lo, th_hi;
+    double h_prox;  // proximal weight on the step lengths in Quu: without the d(h l)/dh term (quirk Q2) the objective does
+                    // not see h at all, the h_k are then fixed by the constraints alone and wander along flat directions
+    int32_t q6, exact_h;
+};
+size_t ilqr_lds_bytes(int32_t N);
+size_t ilqr_scratch_doubles(int32_t B, int32_t N);
+hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z, double* info, double* scratch,
+                          hipStream_t stream);
 hipError_t launch_lqr_cost(const BatchParams& p, const double* qrqf, double dt, double* cost, int cost_batch,
                            hipStream_t stream);
 

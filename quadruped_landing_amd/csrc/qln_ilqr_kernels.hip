@@ -1,0 +1,813 @@
+// qln_ilqr_kernels.hip -- the caller side of the evaluator on the GPU: a batched solve of the
+// reference NLP -- what solve() hands to Ipopt in src/moi.jl:46-103 -- with one wavefront per landing problem.
+//
+// Method: augmented-Lagrangian iLQR.  The NLP is an optimal-control problem: the dynamics rows
+// (src/constraints.jl:6-41) tie x_{k+1} to (x_k, u_k), so the states are eliminated by rolling the controls out from
+// x0 with the evaluator's own RK4 step (the solution's dynamics / initial-condition / contact rows are then zero to
+// the last bit), and a Newton-type step on the controls is a Riccati sweep over the knots -- 15x15 / 15x5 / 5x5 blocks
+// that live in the wave's LDS.  What the roll-out does not satisfy by construction -- the terminal rows
+// (src/constraints.jl:150), the final-control row (:154), the clearance inequalities (:98-113) and solve()'s variable
+// bounds on theta and on the entries quirk Q6 bounds (src/moi.jl:51-67) -- carries multipliers and a quadratic penalty;
+// the bounds on the step length h (a control) are kept inside the sweep (clamped feed-forward, gain row zeroed).
+//   outer loop  : multipliers  lam <- max(0, lam + rho g)  /  lam + rho e ;  rho x10 while the violation stalls
+//   inner loop  : backward Riccati sweep with Levenberg-Marquardt mu on Quu, Gauss-Newton Hessian of the penalty terms;
+//                 forward: ALL step lengths alpha = 1, 1/2, ... tried at once, one lane per alpha, closed-loop
+//                 roll-outs; Armijo on the augmented cost.
+// Objective gradient: by default the reference's own grad_f! (src/costs.jl:23-34), which has no d(h_k l_k)/dh_k
+// (quirk Q2): within an iteration the stage weights h_k are frozen -- the fixed point is the kind of point Ipopt's
+// run tends to with that gradient.  exact_h adds the missing term (a stationary point of the true objective).
+//
+// The step Jacobians A_k, B_k are the closed-form blocks of the evaluator (QLN_STEP_BASE / QLN_STEP_ENTRIES), derived
+// once per sweep by lane = knot and parked in a global scratch (L2-resident: 85 doubles per knot).
+//
+// The reference holds nothing to compare the iterates with (it hands its callbacks to Ipopt 3.13 + MUMPS); the result
+// is checked by the evaluator itself: constraint violation and objective of the returned Z (tests/test_gpu_solve.py).
+#include "qln_kernel_common.h"
+
+#include <cmath>
+
+namespace qln {
+namespace {
+
+constexpr int kAlphas = 16;    // step lengths tried per iteration: 2^0 .. 2^-15
+constexpr int kIneq = 6;       // inequality rows per knot
+constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85 used)
+constexpr int kKn = 16;        // per-knot scalars kept in LDS
+
+// per-knot scalars (lane = knot phase -> backward sweep)
+enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g) */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8, KN_A0 = 9 /* a0..a5 active */, KN_TFC = 15 };
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+struct StageIn {
+    const double* rec;   // cost record [41] (LDS)
+    const double* lam5;  // inequality multipliers of the knot (LDS)
+    double rho, w;       // penalty, weight on the stage cost (h_k, frozen h_k, or 1 for the terminal knot)
+    bool has_u;          // k < N-1
+    bool ineq;           // k >= 1: the knot's inequalities are live (x_1 = x0 is data)
+    bool q6;             // bounds yb >= 0, x1 >= 0 of quirk Q6
+    bool final_ctrl;     // k == N-2
+    bool terminal;       // k == N-1
+    double lam_fc;       // multiplier of the final-control row
+    const double* lam_term;  // [14]
+    const double* xf;        // [15]
+    double mbg, lb, th_lo, th_hi;
+};
+struct StageOut {
+    double val;    // augmented stage cost
+    double ell;    // l_k(x, u) (no weight)
+    double t[kIneq];   // max(0, lam_j + rho g_j)
+    double g[kIneq];   // constraint values g_j <= 0
+    double cq;         // (lb/2) cos(theta): d g0 / d theta = +cq, d g1 / d theta = -cq
+    double e_fc;   // final-control residual
+    double viol;   // largest violation of this knot's constraints
+};
+
+// Augmented-Lagrangian stage cost of one knot (src/costs.jl:6-16 for the objective part).  x[15], u[5] in registers.
+__device__ __forceinline__ void stage_eval(const StageIn& I, const double (&x)[15], const double (&u)[5], StageOut& o) {
+    double ell = I.rec[40];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) ell += (0.5 * (I.rec[i] * x[i])) * x[i] + I.rec[20 + i] * x[i];
+    if (I.has_u) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ell += (0.5 * (I.rec[15 + i] * u[i])) * u[i] + I.rec[35 + i] * u[i];
+    }
+    o.ell = ell;
+    double val = I.w * ell;
+    double viol = 0.0;
+    double sth, cth;
+    sincos(x[2], &sth, &cth);
+    // Clearance yb - (lb/2)|sin theta| >= 0 (src/constraints.jl:98-113) as the two smooth rows it is the intersection
+    // of, yb -+ (lb/2) sin theta >= 0: same feasible set, no kink at theta = 0 -- where landed trajectories live and
+    // where the kinked row stalls every Newton-type step.
+    o.g[0] = -(x[1] - I.lb / 2 * sth);
+    o.g[1] = -(x[1] + I.lb / 2 * sth);
+    o.cq = (I.lb / 2) * cth;
+    o.g[2] = x[2] - I.th_hi;                          // theta <= pi/2                  (src/moi.jl:55-56)
+    o.g[3] = I.th_lo - x[2];
+    o.g[4] = -x[1];                                   // Q6: "22 + 20(k-1)" = yb_{k+1}   (src/moi.jl:64)
+    o.g[5] = -x[3];                                   // Q6: "24 + 20(k-1)" = x1_{k+1}   (src/moi.jl:65)
+#pragma unroll
+    for (int j = 0; j < kIneq; ++j) {
+        const bool on = I.ineq && (j < 4 || I.q6);
+        const double l = I.lam5[j];
+        const double t = on ? fmax(0.0, l + I.rho * o.g[j]) : 0.0;
+        o.t[j] = t;
+        if (on) {
+            val += (t * t - l * l) / (2 * I.rho);
+            viol = fmax(viol, o.g[j]);
+        }
+    }
+    o.e_fc = 0.0;
+    if (I.final_ctrl) {                               // F1y + F2y + mb g = 0               (src/constraints.jl:154)
+        o.e_fc = u[1] + u[3] + I.mbg;
+        val += I.lam_fc * o.e_fc + 0.5 * I.rho * o.e_fc * o.e_fc;
+        viol = fmax(viol, fabs(o.e_fc));
+    }
+    if (I.terminal) {                                 // x_N[1:14] = xf[1:14]               (src/constraints.jl:150)
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const double e = x[i] - I.xf[i];
+            val += I.lam_term[i] * e + 0.5 * I.rho * e * e;
+            viol = fmax(viol, fabs(e));
+        }
+    }
+    o.val = val;
+    o.viol = viol;
+}
+
+// one dynamics knot of the roll-out: the evaluator's RK4 step + jump map (src/constraints.jl:19-38)
+__device__ __forceinline__ void step_forward(const BatchParams& P, int k, int kt, int im, double Ib, const double (&x)[15],
+                                             const double (&u)[5], double (&xn)[15]) {
+    const int K = k + 1;
+    const int mode = (K <= kt - 1) ? im : 3;
+    const bool jump = (K == kt - 1);
+    const bool f1free = (mode == 2), f2free = (mode == 1);
+    StepConst sc;
+    sc.abx = (u[0] + u[2]) / P.mb;
+    sc.aby = (u[1] + u[3]) / P.mb + P.g;
+    sc.a1x = f1free ? (-u[0] / P.mf) : 0.0;
+    sc.a1y = f1free ? (-u[1] / P.mf + P.g) : 0.0;
+    sc.a2x = f2free ? (-u[2] / P.mf) : 0.0;
+    sc.a2y = f2free ? (-u[3] / P.mf + P.g) : 0.0;
+    rk4_step(x, u, sc, f1free, f2free, Ib, xn);
+    if (jump) {
+        xn[4] = 0.0;
+        xn[6] = 0.0;
+        xn[10] = xn[11] = xn[12] = xn[13] = 0.0;
+    }
+}
+
+struct Lds {
+    double *X, *U, *Xt, *Ut, *K, *D, *lam, *leq, *kn, *cost, *P, *pv, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *Qx, *Qu, *g, *Hd;
+    int* map;  // union-pattern position -> offset in [A | B]
+};
+
+// one statement of the LDS layout, walked by the kernel (base = the dynamic LDS) and by the host (base = null: only
+// the size is wanted)
+__host__ __device__ inline size_t carve(double* base, int N, Lds* L) {
+    size_t off = 0;
+    auto take = [&](int n) {
+        double* r = base ? base + off : nullptr;
+        off += (size_t)((n + 1) & ~1);
+        return r;
+    };
+    Lds t;
+    t.X = take(15 * N);
+    t.U = take(5 * N);
+    t.Xt = take(15 * N);
+    t.Ut = take(5 * N);
+    t.K = take(75 * N);
+    t.D = take(5 * N);
+    t.lam = take(kIneq * N);
+    t.leq = take(16);
+    t.kn = take(kKn * N);
+    t.cost = take(41 * N);
+    t.P = take(225);
+    t.pv = take(16);
+    t.A = take(300);  // A (15x15) then B (15x5)
+    t.B = t.A ? t.A + 225 : nullptr;
+    t.T = take(225);
+    t.S = take(75);
+    t.Qxx = take(225);
+    t.Qux = take(75);
+    t.Quu = take(32);
+    t.Qx = take(16);
+    t.Qu = take(8);
+    t.g = take(20);
+    t.Hd = take(32);
+    t.map = reinterpret_cast<int*>(take(kStepUnion / 2 + 2));
+    if (L) *L = t;
+    return off;
+}
+
+}  // namespace
+
+size_t ilqr_lds_bytes(int32_t N) { return carve(nullptr, N, nullptr) * sizeof(double); }
+size_t ilqr_scratch_doubles(int32_t B, int32_t N) { return (size_t)B * (size_t)N * kEnt; }
+
+namespace {
+
+// info[b][16]: 0 outer iterations, 1 iLQR iterations, 2 objective f of the returned Z, 3 constraint violation (the
+// solver's own measure: c rows it penalises + the bounds it penalises), 4 final rho, 5 status (0 = converged to tol,
+// 1 = outer limit reached, 2 = no descent step found at the last penalty), 6 augmented cost, 7 last accepted alpha,
+// 8 sum of h, 9 LM mu at exit
+__global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams S, double* __restrict__ Zio,
+                                                      double* __restrict__ info, double* __restrict__ scratch) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int b = xcd_contiguous_index(blockIdx.x, P.B);
+    if (b >= P.B) return;  // wave-uniform
+    const int N = P.N;
+    const ProblemDesc pd = P.desc[b];
+    const int kt = pd.k_trans, im = pd.init_mode;
+    const double Ib = P.mb * (P.lb * P.lb) / 12;
+    const double mbg = P.mb * P.g;
+    Lds L;
+    carve(lds, N, &L);
+    double* __restrict__ Zb = Zio + (int64_t)b * P.z_stride;
+    double* __restrict__ ent = scratch + (int64_t)b * N * kEnt;
+    const double* __restrict__ x0g = P.bnd + (int64_t)b * 30;
+
+    // ---- load: controls of the initial guess, cost records, boundary states; multipliers start at zero ----
+    {
+        const double* __restrict__ cg = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+        for (int i = lane; i < 41 * N; i += kWave) L.cost[i] = cg[i];
+        for (int i = lane; i < 5 * (N - 1); i += kWave) {
+            const int k = i / 5, j = i - 5 * k;
+            double v = Zb[20 * k + 15 + j];
+            if (j == 4) v = fmin(fmax(v, S.h_lo), S.h_hi);
+            L.U[i] = v;
+        }
+        for (int i = lane; i < kIneq * N; i += kWave) L.lam[i] = 0.0;
+        if (lane < 16) L.leq[lane] = 0.0;
+        if (lane < 15) L.X[lane] = x0g[lane];
+        if (lane < 15) L.Xt[lane] = x0g[lane];
+        // where the p-th entry of a step block's union pattern goes in [A | B] (the value expressions of the
+        // statements are not expanded here: the macro parameter is unused)
+#define JW(row, col, val)                                                                        \
+    {                                                                                            \
+        constexpr int pos_ = step_union_pos(row, col);                                           \
+        if (lane == (pos_ & 63)) L.map[pos_] = ((col) < 15) ? 15 * (row) + (col) : 225 + 5 * (row) + ((col) - 15); \
+    }
+        QLN_STEP_ENTRIES();
+#undef JW
+    }
+    wave_lds_sync();
+    double xf[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) xf[i] = x0g[15 + i];
+
+    auto stage_in = [&](int k, double rho, double w) {
+        StageIn I;
+        I.rec = L.cost + 41 * k;
+        I.lam5 = L.lam + kIneq * k;
+        I.rho = rho;
+        I.w = w;
+        I.has_u = k < N - 1;
+        I.ineq = k >= 1;
+        I.q6 = S.q6 != 0;
+        I.final_ctrl = (k == N - 2);
+        I.terminal = (k == N - 1);
+        I.lam_fc = L.leq[14];
+        I.lam_term = L.leq;
+        I.xf = xf;
+        I.mbg = mbg;
+        I.lb = P.lb;
+        I.th_lo = S.th_lo;
+        I.th_hi = S.th_hi;
+        return I;
+    };
+
+    // ---- initial roll-out of the guess's controls from x0 (every lane redundantly; lane 0's copy is kept) ----
+    {
+        double x[15], u[5], xn[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) x[i] = L.X[i];
+        for (int k = 0; k < N - 1; ++k) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j];
+            step_forward(P, k, kt, im, Ib, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < 15; ++i) x[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 15; ++i) L.X[15 * (k + 1) + i] = xn[i];
+            }
+        }
+    }
+    wave_lds_sync();
+
+    double rho = S.rho0, mu = S.mu0;
+    double prev_viol = INFINITY;
+    double J_cur = 0.0, viol = INFINITY, last_alpha = 0.0;
+    int outer = 0, iters = 0, status = 1;
+
+    // Per-knot scalars at the current trajectory (lane = knot): weights, active multipliers, clearance slope, l_k.
+    // Returns the augmented cost J and the violation (wave-uniform).
+    auto refresh = [&](double& J, double& vmax) {
+        double Jl = 0.0, vl = 0.0;
+        for (int k0 = 0; k0 < N; k0 += kWave) {
+            const int k = k0 + lane;
+            if (k < N) {
+                double x[15], u[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 15; ++i) x[i] = L.X[15 * k + i];
+                if (k < N - 1) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j];
+                }
+                const double w = (k < N - 1) ? u[4] : 1.0;
+                StageIn I = stage_in(k, rho, w);
+                StageOut o;
+                stage_eval(I, x, u, o);
+                double* kn = L.kn + kKn * k;
+                kn[KN_W] = w;
+#pragma unroll
+                for (int j = 0; j < kIneq; ++j) {
+                    kn[KN_T0 + j] = o.t[j];
+                    kn[KN_A0 + j] = o.t[j] > 0 ? 1.0 : 0.0;
+                }
+                kn[KN_CQ] = o.cq;
+                kn[KN_ELL] = o.ell;
+                kn[KN_TFC] = (k == N - 2) ? (L.leq[14] + rho * o.e_fc) : 0.0;
+                Jl += o.val;
+                vl = fmax(vl, o.viol);
+            }
+        }
+        J = wsum(Jl);
+        vmax = wmax(vl);
+        wave_lds_sync();
+    };
+
+    refresh(J_cur, viol);
+    for (outer = 0; outer < S.max_outer; ++outer) {
+        mu = S.mu0;
+        bool stalled = false;
+        for (int it = 0; it < S.max_inner; ++it) {
+            refresh(J_cur, viol);
+            ++iters;
+            // ---- step blocks of every knot (lane = knot), closed form, to the scratch ----
+            for (int k0 = 0; k0 < N - 1; k0 += kWave) {
+                const int k = k0 + lane;
+                if (k < N - 1) {
+                    const double* zk = L.X + 15 * k;
+                    double x[14];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) x[i] = zk[i];
+                    const double F1x = L.U[5 * k], F1y = L.U[5 * k + 1], F2x = L.U[5 * k + 2], F2y = L.U[5 * k + 3], h = L.U[5 * k + 4];
+                    const int K = k + 1;
+                    const int mode = (K <= kt - 1) ? im : 3;
+                    const bool jump = (K == kt - 1), f1free = (mode == 2), f2free = (mode == 1);
+                    const double g = P.g, mb = P.mb, mf = P.mf;
+                    QLN_STEP_BASE();
+                    double* e = ent + (int64_t)k * kEnt;
+#define JW(row, col, val)                              \
+    {                                                  \
+        constexpr int pos_ = step_union_pos(row, col); \
+        e[pos_] = (val);                               \
+    }
+                    QLN_STEP_ENTRIES();
+#undef JW
+                }
+            }
+            __threadfence();  // the entries are read back by other lanes of this wave
+            wave_lds_sync();
+
+            // ---- backward Riccati sweep ----
+            bool pd_ok = true;
+            {
+                // terminal knot: P = Hxx(N-1), pv = gx(N-1)
+                const int k = N - 1;
+                const double* kn = L.kn + kKn * k;
+                const double* rec = L.cost + 41 * k;
+                for (int e = lane; e < 225; e += kWave) L.P[e] = 0.0;
+                wave_lds_sync();
+                if (lane < 15) {
+                    const int i = lane;
+                    const double xi = L.X[15 * k + i];
+                    double gi = rec[i] * xi + rec[20 + i];
+                    double hi = rec[i];
+                    if (i < 14) {
+                        gi += L.leq[i] + rho * (xi - xf[i]);
+                        hi += rho;
+                    }
+                    if (i == 1) {
+                        gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
+                        hi += rho * (kn[KN_A0 + 0] + kn[KN_A0 + 1] + kn[KN_A0 + 4]);
+                    }
+                    if (i == 2) {
+                        gi += (kn[KN_T0 + 0] - kn[KN_T0 + 1]) * kn[KN_CQ] + kn[KN_T0 + 2] - kn[KN_T0 + 3];
+                        hi += rho * ((kn[KN_A0 + 0] + kn[KN_A0 + 1]) * kn[KN_CQ] * kn[KN_CQ] + kn[KN_A0 + 2] + kn[KN_A0 + 3]);
+                    }
+                    if (i == 3) {
+                        gi += -kn[KN_T0 + 5];
+                        hi += rho * kn[KN_A0 + 5];
+                    }
+                    L.pv[i] = gi;
+                    L.P[16 * i] = hi;
+                }
+                if (lane == 0) {
+                    const double off = -rho * (kn[KN_A0 + 0] - kn[KN_A0 + 1]) * kn[KN_CQ];
+                    L.P[15 * 1 + 2] = off;
+                    L.P[15 * 2 + 1] = off;
+                }
+                wave_lds_sync();
+            }
+            for (int k = N - 2; k >= 0 && pd_ok; --k) {
+                const double* kn = L.kn + kKn * k;
+                const double* rec = L.cost + 41 * k;
+                const double w = kn[KN_W];
+                // A (15x15), B (15x5) from the scratch entries
+                for (int e = lane; e < 300; e += kWave) L.A[e] = 0.0;  // A and B
+                wave_lds_sync();
+                {
+                    const double* e = ent + (int64_t)k * kEnt;
+                    const double v0 = e[lane], v1 = e[min(lane + 64, kStepUnion - 1)];
+                    L.A[L.map[lane]] = v0;
+                    if (lane + 64 < kStepUnion) L.A[L.map[lane + 64]] = v1;
+                }
+                // stage gradient (20) and the Gauss-Newton Hessian: diagonal + the (yb, theta) and (F1y, F2y) couplings
+                if (lane < 20) {
+                    const int i = lane;
+                    const double zi = (i < 15) ? L.X[15 * k + i] : L.U[5 * k + (i - 15)];
+                    double gi = w * (rec[i] * zi + rec[20 + i]);
+                    double hi = w * rec[i];
+                    if (k >= 1) {
+                        if (i == 1) {
+                            gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
+                            hi += rho * (kn[KN_A0 + 0] + kn[KN_A0 + 1] + kn[KN_A0 + 4]);
+                        }
+                        if (i == 2) {
+                            gi += (kn[KN_T0 + 0] - kn[KN_T0 + 1]) * kn[KN_CQ] + kn[KN_T0 + 2] - kn[KN_T0 + 3];
+                            hi += rho * ((kn[KN_A0 + 0] + kn[KN_A0 + 1]) * kn[KN_CQ] * kn[KN_CQ] + kn[KN_A0 + 2] + kn[KN_A0 + 3]);
+                        }
+                        if (i == 3) {
+                            gi += -kn[KN_T0 + 5];
+                            hi += rho * kn[KN_A0 + 5];
+                        }
+                    }
+                    if (k == N - 2 && (i == 16 || i == 18)) {
+                        gi += kn[KN_TFC];
+                        hi += rho;
+                    }
+                    if (S.exact_h && i == 19) gi += kn[KN_ELL];  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
+                    L.g[i] = gi;
+                    L.Hd[i] = hi;
+                }
+                wave_lds_sync();
+                const double h12 = (k >= 1) ? -rho * (kn[KN_A0 + 0] - kn[KN_A0 + 1]) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
+                const double hfc = (k == N - 2) ? rho : 0.0;                              // d2/d(F1y)d(F2y)
+                // T = P A, S = P B
+                for (int e = lane; e < 225; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.A[15 * i + c], acc);
+                    L.T[e] = acc;
+                }
+                for (int e = lane; e < 75; e += kWave) {
+                    const int r = e / 5, c = e - 5 * r;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.B[5 * i + c], acc);
+                    L.S[e] = acc;
+                }
+                wave_lds_sync();
+                // Qxx = Hxx + A'T, Qux = B'T, Quu = Huu + B'S + mu I, Qx = gx + A'pv, Qu = gu + B'pv
+                for (int e = lane; e < 225; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double acc = (r == c) ? L.Hd[r] : 0.0;
+                    if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.A[15 * i + r], L.T[15 * i + c], acc);
+                    L.Qxx[e] = acc;
+                }
+                for (int e = lane; e < 75; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;  // r: control, c: state
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.T[15 * i + c], acc);
+                    L.Qux[e] = acc;
+                }
+                if (lane < 25) {
+                    const int r = lane / 5, c = lane - 5 * r;
+                    double acc = (r == c) ? L.Hd[15 + r] + mu : 0.0;
+                    if (r == 4 && c == 4) acc += S.h_prox;  // proximal weight on the step length (see SolveParams)
+                    if ((r == 1 && c == 3) || (r == 3 && c == 1)) acc += hfc;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.S[5 * i + c], acc);
+                    L.Quu[lane] = acc;
+                } else if (lane >= 32 && lane < 47) {
+                    const int r = lane - 32;
+                    double acc = L.g[r];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.A[15 * i + r], L.pv[i], acc);
+                    L.Qx[r] = acc;
+                } else if (lane >= 48 && lane < 53) {
+                    const int r = lane - 48;
+                    double acc = L.g[15 + r];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.pv[i], acc);
+                    L.Qu[r] = acc;
+                }
+                wave_lds_sync();
+                // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every lane alike
+                double q[5][5], l[5][5], dd[5], dinv[5];
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) q[r][c] = L.Quu[5 * r + c];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    double dj = q[j][j];
+#pragma unroll
+                    for (int m = 0; m < j; ++m) dj -= l[j][m] * l[j][m] * dd[m];
+                    if (!(dj > 1e-300)) pd_ok = false;
+                    dd[j] = dj;
+                    dinv[j] = 1.0 / dj;
+#pragma unroll
+                    for (int i = j + 1; i < 5; ++i) {
+                        double v = q[i][j];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) v -= l[i][m] * l[j][m] * dd[m];
+                        l[i][j] = v * dinv[j];
+                    }
+                }
+                if (!pd_ok) break;  // wave-uniform: every lane factors the same matrix
+                // solve Quu y = rhs for the first n unknowns (n = 5, or 4 with h clamped)
+                auto ldl_solve = [&](double (&y)[5], int n) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        if (i < n) {
+#pragma unroll
+                            for (int m = 0; m < i; ++m) y[i] -= l[i][m] * y[m];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if (i < n) y[i] *= dinv[i];
+#pragma unroll
+                    for (int i = 4; i >= 0; --i) {
+                        if (i < n) {
+#pragma unroll
+                            for (int m = i + 1; m < 5; ++m)
+                                if (m < n) y[i] -= l[m][i] * y[m];
+                        }
+                    }
+                };
+                // feed-forward (every lane), with the box on h: clamp, then re-solve the free 4x4
+                double dff[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) dff[i] = -L.Qu[i];
+                ldl_solve(dff, 5);
+                const double hk = L.U[5 * k + 4];
+                const double lo = S.h_lo - hk, hi = S.h_hi - hk;
+                const bool clamped = (dff[4] < lo) || (dff[4] > hi);
+                if (clamped) {
+                    const double hc = fmin(fmax(dff[4], lo), hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dff[i] = -(L.Qu[i] + q[i][4] * hc);
+                    dff[4] = 0.0;
+                    ldl_solve(dff, 4);
+                    dff[4] = hc;
+                }
+                // gains: lane j < 15 solves column j
+                double kc[5] = {0, 0, 0, 0, 0};
+                if (lane < 15) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[15 * i + lane];
+                    if (clamped) {
+                        kc[4] = 0.0;
+                        ldl_solve(kc, 4);
+                        kc[4] = 0.0;
+                    } else {
+                        ldl_solve(kc, 5);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) L.K[75 * k + 15 * i + lane] = kc[i];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) L.D[5 * k + i] = dff[i];
+                }
+                wave_lds_sync();
+                // M = Quu K + Qux (5x15) -> S (reused); m5 = Quu d + Qu
+                for (int e = lane; e < 75; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double acc = L.Qux[e];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) acc = fma(q[r][i], L.K[75 * k + 15 * i + c], acc);
+                    L.S[e] = acc;
+                }
+                double m5[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    double acc = L.Qu[i];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) acc += q[i][j] * dff[j];
+                    m5[i] = acc;
+                }
+                wave_lds_sync();
+                // P <- Qxx + K'M + Qux'K (-> T, then symmetrised into P);  pv <- Qx + K'm5 + Qux'd
+                for (int e = lane; e < 225; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double acc = L.Qxx[e];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        acc = fma(L.K[75 * k + 15 * i + r], L.S[15 * i + c], acc);
+                        acc = fma(L.Qux[15 * i + r], L.K[75 * k + 15 * i + c], acc);
+                    }
+                    L.T[e] = acc;
+                }
+                if (lane < 15) {
+                    double acc = L.Qx[lane];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        acc = fma(L.K[75 * k + 15 * i + lane], m5[i], acc);
+                        acc = fma(L.Qux[15 * i + lane], dff[i], acc);
+                    }
+                    L.pv[lane] = acc;
+                }
+                wave_lds_sync();
+                for (int e = lane; e < 225; e += kWave) {
+                    const int r = e / 15, c = e - 15 * r;
+                    L.P[e] = 0.5 * (L.T[e] + L.T[15 * c + r]);
+                }
+                wave_lds_sync();
+            }
+            if (!pd_ok) {
+                mu = fmin(mu * 10.0, S.mu_max);
+                if (mu >= S.mu_max) {
+                    stalled = true;
+                    break;
+                }
+                continue;
+            }
+
+            // ---- forward: one closed-loop roll-out per step length, lane a tries alpha = 2^-a ----
+            double J_try = INFINITY;
+            const double alpha = (lane < kAlphas) ? ldexp(1.0, -lane) : 0.0;
+            if (lane < kAlphas) {
+                double x[15], u[5], xn[15];
+                double J = 0.0;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) x[i] = L.X[i];
+                for (int k = 0; k < N - 1; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * L.D[5 * k + j];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) {
+                        const double dx = x[i] - L.X[15 * k + i];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) u[j] = fma(L.K[75 * k + 15 * j + i], dx, u[j]);
+                    }
+                    u[4] = fmin(fmax(u[4], S.h_lo), S.h_hi);
+                    const double w = S.exact_h ? u[4] : L.kn[kKn * k + KN_W];
+                    StageIn I = stage_in(k, rho, w);
+                    StageOut o;
+                    stage_eval(I, x, u, o);
+                    J += o.val;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) L.Ut[5 * k + j] = u[j];
+                    }
+                    step_forward(P, k, kt, im, Ib, x, u, xn);
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) x[i] = xn[i];
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) L.Xt[15 * (k + 1) + i] = xn[i];
+                    }
+                }
+                {
+                    double u0[5] = {0, 0, 0, 0, 0};
+                    StageIn I = stage_in(N - 1, rho, 1.0);
+                    StageOut o;
+                    stage_eval(I, x, u0, o);
+                    J += o.val;
+                }
+                J_try = J;
+            }
+            // the best of the sixteen candidates, if any lowers the cost (all were computed anyway: one lane each)
+            double J_best = ((lane < kAlphas) && (J_try == J_try) && (J_try < J_cur)) ? J_try : INFINITY;
+            int a_star = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double Jo = __shfl_xor(J_best, off, kWave);
+                const int ao = __shfl_xor(a_star, off, kWave);
+                if (Jo < J_best || (Jo == J_best && ao < a_star)) {
+                    J_best = Jo;
+                    a_star = ao;
+                }
+            }
+            wave_lds_sync();
+            if (!(J_best < J_cur)) {  // no step length gives descent: more regularisation
+                mu = fmin(mu * 10.0, S.mu_max);
+                if (mu >= S.mu_max) {
+                    stalled = true;
+                    break;
+                }
+                continue;
+            }
+            const double J_new = J_best;
+            last_alpha = ldexp(1.0, -a_star);
+            if (a_star != 0) {
+                // the accepted roll-out again, kept this time (every lane redundantly, lane 0 writes)
+                double x[15], u[5], xn[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) x[i] = L.X[i];
+                for (int k = 0; k < N - 1; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + last_alpha * L.D[5 * k + j];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) {
+                        const double dx = x[i] - L.X[15 * k + i];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) u[j] = fma(L.K[75 * k + 15 * j + i], dx, u[j]);
+                    }
+                    u[4] = fmin(fmax(u[4], S.h_lo), S.h_hi);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) L.Ut[5 * k + j] = u[j];
+                    }
+                    step_forward(P, k, kt, im, Ib, x, u, xn);
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) x[i] = xn[i];
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) L.Xt[15 * (k + 1) + i] = xn[i];
+                    }
+                }
+            }
+            wave_lds_sync();
+            {  // accept: the trial trajectory becomes the current one
+                double* t = L.X;
+                L.X = L.Xt;
+                L.Xt = t;
+                t = L.U;
+                L.U = L.Ut;
+                L.Ut = t;
+            }
+            mu = fmax(mu / 3.0, S.mu_min);
+            const double dJ = J_cur - J_new;
+            if (dJ < S.inner_tol * (1.0 + fabs(J_new))) break;
+        }
+        // ---- outer: violation, stop test, multipliers, penalty ----
+        refresh(J_cur, viol);
+        if (viol <= S.tol) {
+            status = 0;
+            ++outer;
+            break;
+        }
+        for (int k0 = 0; k0 < N; k0 += kWave) {
+            const int k = k0 + lane;
+            if (k < N && k >= 1) {
+#pragma unroll
+                for (int j = 0; j < kIneq; ++j) L.lam[kIneq * k + j] = L.kn[kKn * k + KN_T0 + j];  // max(0, lam + rho g)
+            }
+        }
+        if (lane < 14) L.leq[lane] += rho * (L.X[15 * (N - 1) + lane] - xf[lane]);
+        if (lane == 14) L.leq[14] = L.kn[kKn * (N - 2) + KN_TFC];
+        wave_lds_sync();
+        if (viol > 0.25 * prev_viol) rho = fmin(rho * S.rho_factor, S.rho_max);
+        prev_viol = viol;
+        if (stalled && rho >= S.rho_max) status = 2;
+    }
+
+    // ---- write the solution (states of the roll-out: their dynamics rows are exactly zero) and the report ----
+    for (int i = lane; i < 20 * (N - 1); i += kWave) {
+        const int k = i / 20, j = i - 20 * k;
+        Zb[i] = (j < 15) ? L.X[15 * k + j] : L.U[5 * k + (j - 15)];
+    }
+    if (lane < 15) Zb[20 * (N - 1) + lane] = L.X[15 * (N - 1) + lane];
+    {
+        double f = 0.0, hs = 0.0;
+        for (int k0 = 0; k0 < N; k0 += kWave) {
+            const int k = k0 + lane;
+            if (k < N) {
+                const double ell = L.kn[kKn * k + KN_ELL];
+                const double hk = (k < N - 1) ? L.U[5 * k + 4] : 1.0;
+                f += hk * ell;
+                if (k < N - 1) hs += hk;
+            }
+        }
+        f = wsum(f);
+        hs = wsum(hs);
+        if (info && lane == 0) {
+            double* o = info + 16 * (int64_t)b;
+            o[0] = (double)outer;
+            o[1] = (double)iters;
+            o[2] = f;
+            o[3] = viol;
+            o[4] = rho;
+            o[5] = (double)status;
+            o[6] = J_cur;
+            o[7] = last_alpha;
+            o[8] = hs;
+            o[9] = mu;
+            for (int i = 10; i < 16; ++i) o[i] = 0.0;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z, double* info, double* scratch, hipStream_t stream) {
+    const size_t lds = ilqr_lds_bytes(p.N);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_al_ilqr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_al_ilqr, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, s, Z, info, scratch);
+    return hipGetLastError();
+}
+
+}  // namespace qln

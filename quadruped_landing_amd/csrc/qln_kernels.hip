@@ -50,61 +50,6 @@ namespace {
 #define QLN_STAMP(i) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// Value path: literal restatement of contact{1,2,3}_dynamics (src/planar_quadruped.jl:36-185).
-// f1free/f2free select the mode: mode 1 = foot 2 free, mode 2 = foot 1 free, mode 3 = none.
-// ---------------------------------------------------------------------------------------------
-struct StepConst {
-    double abx, aby;    // body acceleration
-    double a1x, a1y;    // foot 1 acceleration (0 if pinned)
-    double a2x, a2y;    // foot 2 acceleration (0 if pinned)
-};
-
-__device__ __forceinline__ void dynamics(const double (&s)[14], const double (&u)[5], const StepConst& k, bool f1free,
-                                         bool f2free, double Ib, double (&f)[14]) {
-    const double F1x = u[0], F1y = u[1], F2x = u[2], F2y = u[3];
-    // tauF = -F1x*(p1[2]-pb[2]) + F1y*(p1[1]-pb[1]) - F2x*(p2[2]-pb[2]) + F2y*(p2[1]-pb[1])
-    const double tauF = -F1x * (s[4] - s[1]) + F1y * (s[3] - s[0]) - F2x * (s[6] - s[1]) + F2y * (s[5] - s[0]);
-    f[0] = s[7];
-    f[1] = s[8];
-    f[2] = s[9];
-    f[3] = f1free ? s[10] : 0.0;
-    f[4] = f1free ? s[11] : 0.0;
-    f[5] = f2free ? s[12] : 0.0;
-    f[6] = f2free ? s[13] : 0.0;
-    f[7] = k.abx;
-    f[8] = k.aby;
-    f[9] = tauF / Ib;
-    f[10] = k.a1x;
-    f[11] = k.a1y;
-    f[12] = k.a2x;
-    f[13] = k.a2y;
-}
-
-// contact*_dynamics_rk4 (src/planar_quadruped.jl:189-221)
-__device__ __forceinline__ void rk4_step(const double (&x)[15], const double (&u)[5], const StepConst& k, bool f1free,
-                                         bool f2free, double Ib, double (&xn)[15]) {
-    const double h = u[4];
-    const double hh = 0.5 * h;
-    double s0[14], s[14], f1[14], f2[14], f3[14], f4[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) s0[i] = x[i];
-    dynamics(s0, u, k, f1free, f2free, Ib, f1);
-#pragma unroll
-    for (int i = 0; i < 14; ++i) s[i] = s0[i] + hh * f1[i];
-    dynamics(s, u, k, f1free, f2free, Ib, f2);
-#pragma unroll
-    for (int i = 0; i < 14; ++i) s[i] = s0[i] + hh * f2[i];
-    dynamics(s, u, k, f1free, f2free, Ib, f3);
-#pragma unroll
-    for (int i = 0; i < 14; ++i) s[i] = s0[i] + h * f3[i];
-    dynamics(s, u, k, f1free, f2free, Ib, f4);
-    const double h6 = h / 6.0;
-#pragma unroll
-    for (int i = 0; i < 14; ++i) xn[i] = s0[i] + h6 * (((f1[i] + 2 * f2[i]) + 2 * f3[i]) + f4[i]);
-    xn[14] = x[14] + u[4];
-}
-
 // Copy consecutive 1-KiB wave pieces (16 B per lane each) LDS -> global with all the batch's
 // ds_read_b128 in flight before the first store, so a batch pays the LDS latency once.  hipcc
 // re-interleaves any C++ formulation into read/wait/store through one register quad (or parks the

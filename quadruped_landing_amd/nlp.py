@@ -413,6 +413,25 @@ class HybridNLP:
                                                     ptr(info, _lib.GN_INFO_STRIDE * self.B, "info")))
         return out
 
+    def solve(self, Z, info=None, **options):
+        """Batched solve of the reference NLP (solve(), src/moi.jl:46-103) on the GPU, in place on `Z` (device tensor,
+        layout of Z; the controls of the guess are used, the states are rolled out from x0).  `options`: fields of
+        qln_solve_options (max_outer, max_inner, tol_violation, rho0, ..., q6_bounds, exact_h_gradient).
+        Returns (Z, info) with info a (B, 16) tensor: outer iterations, iLQR iterations, f, violation, rho, status, ..."""
+        t = _torch()
+        self._check(Z, self.dims.z_total, "Z")
+        if info is None:
+            info = t.zeros(self.B * _lib.SOLVE_INFO_STRIDE, dtype=t.float64, device=self._dev())
+        self._check(info, self.B * _lib.SOLVE_INFO_STRIDE, "info")
+        opt = _lib.QlnSolveOptions()
+        _lib.check(_lib.lib().qln_solve_default_options(C.byref(opt)))
+        for k, v in options.items():
+            if not hasattr(opt, k):
+                raise TypeError(f"unknown solve option {k!r}")
+            setattr(opt, k, v)
+        _lib.check(_lib.lib().qln_solve(self._h, Z.data_ptr(), C.byref(opt), info.data_ptr()))
+        return Z, info.view(self.B, _lib.SOLVE_INFO_STRIDE)
+
     def constraint_violation(self, c, out=None):
         """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
         out = self.new_f() if out is None else out
