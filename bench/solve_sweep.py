@@ -13,7 +13,7 @@ batch = PG.make_batch(B, N, kt, 1, seed=3, noise=0.0)
 nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
 Z0 = nlp.initial_guess()
 torch.cuda.synchronize()
-sets = [dict(), dict(h_prox=1e2), dict(h_prox=1e6), dict(h_prox=0.0), dict(rho_max=1e6, max_outer=40), dict(exact_h_gradient=1), dict(exact_h_gradient=1, h_prox=0.0), dict(max_inner=100)]
+sets = [dict(), dict(exact_h_gradient=1)]
 for opts in sets:
     Z = Z0.clone()
     torch.cuda.synchronize()
@@ -36,3 +36,6 @@ print("not converged:", bad[:40].tolist())
 for b in bad[:12]:
     print(b, "outer %d iters %d viol %.2e rho %.0e status %d J %.6f alpha %.3g mu %.1e x0: th %.3f y2 %.3f vby %.3f w %.3f" % (
         inf[b,0], inf[b,1], inf[b,3], inf[b,4], inf[b,5], inf[b,6], inf[b,7], inf[b,9], batch.x0[b,2], batch.x0[b,6], batch.x0[b,8], batch.x0[b,9]))
+tk = inf[:, 10:15]
+print("phase ticks per iLQR iteration (median over problems): refresh %.0f  blocks %.0f  sweep %.0f  rollouts %.0f  accept %.0f  (s_memtime ticks)" % tuple(np.median(tk / inf[:, 1:2], axis=0)))
+print("share: ", np.round(np.median(tk / tk.sum(axis=1, keepdims=True), axis=0), 3))

@@ -33,6 +33,7 @@ constexpr int kAlphas = 16;    // step lengths tried per iteration: 2^0 .. 2^-15
 constexpr int kIneq = 6;       // inequality rows per knot
 constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85 used)
 constexpr int kKn = 16;        // per-knot scalars kept in LDS
+constexpr int kKg = 80;        // doubles per knot of the feedback gains in the scratch (5 rows of 15, padded to 16)
 
 // per-knot scalars (lane = knot phase -> backward sweep)
 enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g) */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8, KN_A0 = 9 /* a0..a5 active */, KN_TFC = 15 };
@@ -49,7 +50,7 @@ __device__ __forceinline__ double wmax(double v) {
 }
 
 struct StageIn {
-    const double* rec;   // cost record [41] (LDS)
+    const double* rec;   // cost record [41] (global, wave-uniform address)
     const double* lam5;  // inequality multipliers of the knot (LDS)
     double rho, w;       // penalty, weight on the stage cost (h_k, frozen h_k, or 1 for the terminal knot)
     bool has_u;          // k < N-1
@@ -84,14 +85,20 @@ __device__ __forceinline__ void stage_eval(const StageIn& I, const double (&x)[1
     o.ell = ell;
     double val = I.w * ell;
     double viol = 0.0;
-    double sth, cth;
-    sincos(x[2], &sth, &cth);
     // Clearance yb - (lb/2)|sin theta| >= 0 (src/constraints.jl:98-113) as the two smooth rows it is the intersection
     // of, yb -+ (lb/2) sin theta >= 0: same feasible set, no kink at theta = 0 -- where landed trajectories live and
-    // where the kinked row stalls every Newton-type step.
-    o.g[0] = -(x[1] - I.lb / 2 * sth);
-    o.g[1] = -(x[1] + I.lb / 2 * sth);
-    o.cq = (I.lb / 2) * cth;
+    // where the kinked row stalls every Newton-type step.  With zero multipliers and yb > lb/2 both rows are inactive
+    // whatever theta is (|sin| <= 1): the trigonometry is skipped and the result is the same.
+    if (I.ineq && (I.lam5[0] > 0 || I.lam5[1] > 0 || !(x[1] > I.lb / 2))) {
+        double sth, cth;
+        sincos(x[2], &sth, &cth);
+        o.g[0] = -(x[1] - I.lb / 2 * sth);
+        o.g[1] = -(x[1] + I.lb / 2 * sth);
+        o.cq = (I.lb / 2) * cth;
+    } else {
+        o.g[0] = o.g[1] = I.lb / 2 - x[1];  // an upper bound of both rows, negative here
+        o.cq = 0.0;
+    }
     o.g[2] = x[2] - I.th_hi;                          // theta <= pi/2                  (src/moi.jl:55-56)
     o.g[3] = I.th_lo - x[2];
     o.g[4] = -x[1];                                   // Q6: "22 + 20(k-1)" = yb_{k+1}   (src/moi.jl:64)
@@ -147,53 +154,87 @@ __device__ __forceinline__ void step_forward(const BatchParams& P, int k, int kt
     }
 }
 
+// Structure of a step block that the Riccati sweep relies on (checked against the union pattern of qln_device.h):
+//   d x+/d x (15x15): the diagonal, rows 2 (theta) and 9 (omega), and (c-7, c) for c in {7, 8, 10, 11, 12, 13}
+//                     (a position picks up h times its velocity);
+//   d x+/d F (columns 15-18): six rows each -- b_rows(j);   d x+/d h (column 19): dense.
+__host__ __device__ constexpr int a_coupling(int c) { return (c == 7 || c == 8 || (c >= 10 && c <= 13)) ? c - 7 : -1; }
+__host__ __device__ constexpr void b_rows(int j, int (&rows)[6]) {
+    rows[0] = j & 1;
+    rows[1] = 2;
+    rows[2] = 3 + j;
+    rows[3] = 7 + (j & 1);
+    rows[4] = 9;
+    rows[5] = 10 + j;
+}
+constexpr bool step_structure_ok() {
+    for (int r = 0; r < 15; ++r) {
+        for (int c = 0; c < 15; ++c)
+            if (step_union_present(r, c) && !(r == c || r == 2 || r == 9 || r == a_coupling(c))) return false;
+        for (int j = 0; j < 4; ++j) {
+            int rows[6] = {0, 0, 0, 0, 0, 0};
+            b_rows(j, rows);
+            bool in = false;
+            for (int q = 0; q < 6; ++q) in = in || rows[q] == r;
+            if (step_union_present(r, 15 + j) && !in) return false;
+        }
+    }
+    return true;
+}
+static_assert(step_structure_ok(), "the sparse products of the Riccati sweep cover every possible non-zero of a step block");
+
 struct Lds {
-    double *X, *U, *Xt, *Ut, *K, *D, *lam, *leq, *kn, *cost, *P, *pv, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *Qx, *Qu, *g, *Hd;
+    double *X, *U, *K, *D, *lam, *leq, *kn, *P, *pv, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *Qx, *Qu, *g, *Hd;
     int* map;  // union-pattern position -> offset in [A | B]
 };
 
-// one statement of the LDS layout, walked by the kernel (base = the dynamic LDS) and by the host (base = null: only
-// the size is wanted)
-__host__ __device__ inline size_t carve(double* base, int N, Lds* L) {
+// One statement of the LDS layout: the kernel carves its pointers out of the dynamic LDS with it (returned BY VALUE --
+// a struct whose address is taken would live in scratch memory, and every LDS access would start with a scratch load),
+// the host gets the size (base = null).
+struct Carved {
+    Lds L;
+    size_t doubles;
+};
+__host__ __device__ __forceinline__ Carved carve(double* base, int N) {
     size_t off = 0;
-    auto take = [&](int n) {
-        double* r = base ? base + off : nullptr;
-        off += (size_t)((n + 1) & ~1);
-        return r;
-    };
-    Lds t;
-    t.X = take(15 * N);
-    t.U = take(5 * N);
-    t.Xt = take(15 * N);
-    t.Ut = take(5 * N);
-    t.K = take(75 * N);
-    t.D = take(5 * N);
-    t.lam = take(kIneq * N);
-    t.leq = take(16);
-    t.kn = take(kKn * N);
-    t.cost = take(41 * N);
-    t.P = take(225);
-    t.pv = take(16);
-    t.A = take(300);  // A (15x15) then B (15x5)
+    Carved cv;
+    Lds& t = cv.L;
+#define QLN_TAKE(field, n)                 \
+    t.field = base ? base + off : nullptr; \
+    off += (size_t)(((n) + 1) & ~1);
+    QLN_TAKE(X, 15 * N)
+    QLN_TAKE(U, 5 * N)
+    QLN_TAKE(K, 80)   // gains of the knot being swept; all knots: global scratch
+    QLN_TAKE(D, 5 * N)
+    QLN_TAKE(lam, kIneq * N)
+    QLN_TAKE(leq, 16)
+    QLN_TAKE(kn, kKn * N)
+    QLN_TAKE(P, 225)
+    QLN_TAKE(pv, 16)
+    QLN_TAKE(A, 300)  // A (15x15) then B (15x5)
     t.B = t.A ? t.A + 225 : nullptr;
-    t.T = take(225);
-    t.S = take(75);
-    t.Qxx = take(225);
-    t.Qux = take(75);
-    t.Quu = take(32);
-    t.Qx = take(16);
-    t.Qu = take(8);
-    t.g = take(20);
-    t.Hd = take(32);
-    t.map = reinterpret_cast<int*>(take(kStepUnion / 2 + 2));
-    if (L) *L = t;
-    return off;
+    QLN_TAKE(T, 225)
+    QLN_TAKE(S, 75)
+    QLN_TAKE(Qxx, 225)
+    QLN_TAKE(Qux, 75)
+    QLN_TAKE(Quu, 32)
+    QLN_TAKE(Qx, 16)
+    QLN_TAKE(Qu, 8)
+    QLN_TAKE(g, 20)
+    QLN_TAKE(Hd, 32)
+    double* mp = base ? base + off : nullptr;
+    off += (size_t)((kStepUnion / 2 + 2 + 1) & ~1);
+    t.map = reinterpret_cast<int*>(mp);
+#undef QLN_TAKE
+    cv.doubles = off;
+    return cv;
 }
 
 }  // namespace
 
-size_t ilqr_lds_bytes(int32_t N) { return carve(nullptr, N, nullptr) * sizeof(double); }
-size_t ilqr_scratch_doubles(int32_t B, int32_t N) { return (size_t)B * (size_t)N * kEnt; }
+size_t ilqr_lds_bytes(int32_t N) { return carve(nullptr, N).doubles * sizeof(double); }
+// per problem: the step blocks of every knot, and one trial trajectory per step length
+size_t ilqr_scratch_doubles(int32_t B, int32_t N) { return (size_t)B * ((size_t)N * (kEnt + kKg) + (size_t)kAlphas * 20 * (size_t)N); }
 
 namespace {
 
@@ -212,26 +253,31 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     const int kt = pd.k_trans, im = pd.init_mode;
     const double Ib = P.mb * (P.lb * P.lb) / 12;
     const double mbg = P.mb * P.g;
-    Lds L;
-    carve(lds, N, &L);
+    const double p_lb = P.lb;
+    const double h_lo = S.h_lo, h_hi = S.h_hi, th_lo = S.th_lo, th_hi = S.th_hi, h_prox = S.h_prox;
+    const double mu0 = S.mu0, mu_min = S.mu_min, mu_max = S.mu_max, tol = S.tol, inner_tol = S.inner_tol;
+    const double rho_factor = S.rho_factor, rho_max = S.rho_max;
+    const int max_outer = S.max_outer, max_inner = S.max_inner;
+    const bool q6 = S.q6 != 0, exact_h = S.exact_h != 0;
+    const Lds L = carve(lds, N).L;
     double* __restrict__ Zb = Zio + (int64_t)b * P.z_stride;
-    double* __restrict__ ent = scratch + (int64_t)b * N * kEnt;
+    double* __restrict__ ent = scratch + (int64_t)b * ((int64_t)N * (kEnt + kKg) + (int64_t)kAlphas * 20 * N);
+    double* __restrict__ Kg = ent + (int64_t)N * kEnt;    // [N][5][16]: feedback gains of every knot (L2-resident)
+    double* __restrict__ traj = Kg + (int64_t)N * kKg;    // [kAlphas][20 N]: the trial roll-outs, Z layout
+    const double* __restrict__ costg = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);  // wave-uniform reads
     const double* __restrict__ x0g = P.bnd + (int64_t)b * 30;
 
     // ---- load: controls of the initial guess, cost records, boundary states; multipliers start at zero ----
     {
-        const double* __restrict__ cg = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
-        for (int i = lane; i < 41 * N; i += kWave) L.cost[i] = cg[i];
         for (int i = lane; i < 5 * (N - 1); i += kWave) {
             const int k = i / 5, j = i - 5 * k;
             double v = Zb[20 * k + 15 + j];
-            if (j == 4) v = fmin(fmax(v, S.h_lo), S.h_hi);
+            if (j == 4) v = fmin(fmax(v, h_lo), h_hi);
             L.U[i] = v;
         }
         for (int i = lane; i < kIneq * N; i += kWave) L.lam[i] = 0.0;
         if (lane < 16) L.leq[lane] = 0.0;
         if (lane < 15) L.X[lane] = x0g[lane];
-        if (lane < 15) L.Xt[lane] = x0g[lane];
         // where the p-th entry of a step block's union pattern goes in [A | B] (the value expressions of the
         // statements are not expanded here: the macro parameter is unused)
 #define JW(row, col, val)                                                                        \
@@ -247,24 +293,24 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
 #pragma unroll
     for (int i = 0; i < 15; ++i) xf[i] = x0g[15 + i];
 
-    auto stage_in = [&](int k, double rho, double w) {
+    auto stage_in = [=](int k, double rho, double w) {
         StageIn I;
-        I.rec = L.cost + 41 * k;
+        I.rec = costg + 41 * k;
         I.lam5 = L.lam + kIneq * k;
         I.rho = rho;
         I.w = w;
         I.has_u = k < N - 1;
         I.ineq = k >= 1;
-        I.q6 = S.q6 != 0;
+        I.q6 = q6;
         I.final_ctrl = (k == N - 2);
         I.terminal = (k == N - 1);
         I.lam_fc = L.leq[14];
         I.lam_term = L.leq;
         I.xf = xf;
         I.mbg = mbg;
-        I.lb = P.lb;
-        I.th_lo = S.th_lo;
-        I.th_hi = S.th_hi;
+        I.lb = p_lb;
+        I.th_lo = th_lo;
+        I.th_hi = th_hi;
         return I;
     };
 
@@ -287,14 +333,17 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     }
     wave_lds_sync();
 
-    double rho = S.rho0, mu = S.mu0;
+    // where a problem's time goes: s_memtime ticks per phase, reported in info[10..14]
+    unsigned long long tk_refresh = 0, tk_blocks = 0, tk_sweep = 0, tk_roll = 0, tk_accept = 0, tk0;
+#define QLN_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tk0; tk0 = t_; } while (0)
+    double rho = S.rho0, mu = mu0;
     double prev_viol = INFINITY;
     double J_cur = 0.0, viol = INFINITY, last_alpha = 0.0;
     int outer = 0, iters = 0, status = 1;
 
     // Per-knot scalars at the current trajectory (lane = knot): weights, active multipliers, clearance slope, l_k.
     // Returns the augmented cost J and the violation (wave-uniform).
-    auto refresh = [&](double& J, double& vmax) {
+    auto refresh = [=](double rho, double& J, double& vmax) {
         double Jl = 0.0, vl = 0.0;
         for (int k0 = 0; k0 < N; k0 += kWave) {
             const int k = k0 + lane;
@@ -329,13 +378,15 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
         wave_lds_sync();
     };
 
-    refresh(J_cur, viol);
-    for (outer = 0; outer < S.max_outer; ++outer) {
-        mu = S.mu0;
+    refresh(rho, J_cur, viol);
+    for (outer = 0; outer < max_outer; ++outer) {
+        mu = mu0;
         bool stalled = false;
-        for (int it = 0; it < S.max_inner; ++it) {
-            refresh(J_cur, viol);
+        for (int it = 0; it < max_inner; ++it) {
+            tk0 = __builtin_amdgcn_s_memtime();
+            refresh(rho, J_cur, viol);
             ++iters;
+            QLN_TICK(tk_refresh);
             // ---- step blocks of every knot (lane = knot), closed form, to the scratch ----
             for (int k0 = 0; k0 < N - 1; k0 += kWave) {
                 const int k = k0 + lane;
@@ -362,6 +413,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             }
             __threadfence();  // the entries are read back by other lanes of this wave
             wave_lds_sync();
+            QLN_TICK(tk_blocks);
 
             // ---- backward Riccati sweep ----
             bool pd_ok = true;
@@ -369,7 +421,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 // terminal knot: P = Hxx(N-1), pv = gx(N-1)
                 const int k = N - 1;
                 const double* kn = L.kn + kKn * k;
-                const double* rec = L.cost + 41 * k;
+                const double* rec = costg + 41 * k;
                 for (int e = lane; e < 225; e += kWave) L.P[e] = 0.0;
                 wave_lds_sync();
                 if (lane < 15) {
@@ -405,7 +457,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             }
             for (int k = N - 2; k >= 0 && pd_ok; --k) {
                 const double* kn = L.kn + kKn * k;
-                const double* rec = L.cost + 41 * k;
+                const double* rec = costg + 41 * k;
                 const double w = kn[KN_W];
                 // A (15x15), B (15x5) from the scratch entries
                 for (int e = lane; e < 300; e += kWave) L.A[e] = 0.0;  // A and B
@@ -440,65 +492,98 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         gi += kn[KN_TFC];
                         hi += rho;
                     }
-                    if (S.exact_h && i == 19) gi += kn[KN_ELL];  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
+                    if (exact_h && i == 19) gi += kn[KN_ELL];  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
                     L.g[i] = gi;
                     L.Hd[i] = hi;
                 }
                 wave_lds_sync();
                 const double h12 = (k >= 1) ? -rho * (kn[KN_A0 + 0] - kn[KN_A0 + 1]) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
                 const double hfc = (k == N - 2) ? rho : 0.0;                              // d2/d(F1y)d(F2y)
+                // The products of the sweep use the structure of the step blocks instead of dense 15-term sums (see
+                // step_structure_ok below): A = diagonal + rows 2 (theta) and 9 (omega) + the six position <- velocity
+                // couplings (c-7, c); a force column of B has six rows; only the h column of B is dense.
                 // T = P A, S = P B
                 for (int e = lane; e < 225; e += kWave) {
                     const int r = e / 15, c = e - 15 * r;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.A[15 * i + c], acc);
-                    L.T[e] = acc;
+                    const int cp = a_coupling(c);
+                    const double p0 = L.P[e], p2 = L.P[15 * r + 2], p9 = L.P[15 * r + 9], pc = L.P[15 * r + max(cp, 0)];
+                    const double a0 = L.A[16 * c], a2 = (c == 2) ? 0.0 : L.A[30 + c], a9 = (c == 9) ? 0.0 : L.A[135 + c];
+                    const double ac = (cp >= 0) ? L.A[15 * cp + c] : 0.0;
+                    L.T[e] = fma(pc, ac, fma(p9, a9, fma(p2, a2, p0 * a0)));
                 }
                 for (int e = lane; e < 75; e += kWave) {
-                    const int r = e / 5, c = e - 5 * r;
+                    const int r = e / 5, j = e - 5 * r;
                     double acc = 0.0;
+                    if (j < 4) {
+                        int rows[6];
+                        b_rows(j, rows);
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.B[5 * i + c], acc);
+                        for (int q = 0; q < 6; ++q) acc = fma(L.P[15 * r + rows[q]], L.B[5 * rows[q] + j], acc);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.B[5 * i + 4], acc);
+                    }
                     L.S[e] = acc;
                 }
                 wave_lds_sync();
                 // Qxx = Hxx + A'T, Qux = B'T, Quu = Huu + B'S + mu I, Qx = gx + A'pv, Qu = gu + B'pv
                 for (int e = lane; e < 225; e += kWave) {
                     const int r = e / 15, c = e - 15 * r;
+                    const int rp = a_coupling(r);
                     double acc = (r == c) ? L.Hd[r] : 0.0;
                     if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.A[15 * i + r], L.T[15 * i + c], acc);
+                    const double a0 = L.A[16 * r], a2 = (r == 2) ? 0.0 : L.A[30 + r], a9 = (r == 9) ? 0.0 : L.A[135 + r];
+                    const double ac = (rp >= 0) ? L.A[15 * rp + r] : 0.0;
+                    acc = fma(a0, L.T[e], acc);
+                    acc = fma(a2, L.T[30 + c], acc);
+                    acc = fma(a9, L.T[135 + c], acc);
+                    acc = fma(ac, L.T[15 * max(rp, 0) + c], acc);
                     L.Qxx[e] = acc;
                 }
                 for (int e = lane; e < 75; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;  // r: control, c: state
+                    const int j = e / 15, c = e - 15 * j;  // j: control, c: state
                     double acc = 0.0;
+                    if (j < 4) {
+                        int rows[6];
+                        b_rows(j, rows);
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.T[15 * i + c], acc);
+                        for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[15 * rows[q] + c], acc);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + 4], L.T[15 * i + c], acc);
+                    }
                     L.Qux[e] = acc;
                 }
                 if (lane < 25) {
-                    const int r = lane / 5, c = lane - 5 * r;
-                    double acc = (r == c) ? L.Hd[15 + r] + mu : 0.0;
-                    if (r == 4 && c == 4) acc += S.h_prox;  // proximal weight on the step length (see SolveParams)
-                    if ((r == 1 && c == 3) || (r == 3 && c == 1)) acc += hfc;
+                    const int j = lane / 5, c = lane - 5 * j;
+                    double acc = (j == c) ? L.Hd[15 + j] + mu : 0.0;
+                    if (j == 4 && c == 4) acc += h_prox;  // proximal weight on the step length (see SolveParams)
+                    if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
+                    if (j < 4) {
+                        int rows[6];
+                        b_rows(j, rows);
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.S[5 * i + c], acc);
+                        for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.S[5 * rows[q] + c], acc);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + 4], L.S[5 * i + c], acc);
+                    }
                     L.Quu[lane] = acc;
                 } else if (lane >= 32 && lane < 47) {
                     const int r = lane - 32;
+                    const int rp = a_coupling(r);
                     double acc = L.g[r];
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.A[15 * i + r], L.pv[i], acc);
+                    acc = fma(L.A[16 * r], L.pv[r], acc);
+                    if (r != 2) acc = fma(L.A[30 + r], L.pv[2], acc);
+                    if (r != 9) acc = fma(L.A[135 + r], L.pv[9], acc);
+                    if (rp >= 0) acc = fma(L.A[15 * rp + r], L.pv[rp], acc);
                     L.Qx[r] = acc;
                 } else if (lane >= 48 && lane < 53) {
-                    const int r = lane - 48;
-                    double acc = L.g[15 + r];
+                    const int j = lane - 48;
+                    double acc = L.g[15 + j];
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + r], L.pv[i], acc);
-                    L.Qu[r] = acc;
+                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + j], L.pv[i], acc);
+                    L.Qu[j] = acc;
                 }
                 wave_lds_sync();
                 // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every lane alike
@@ -551,7 +636,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 for (int i = 0; i < 5; ++i) dff[i] = -L.Qu[i];
                 ldl_solve(dff, 5);
                 const double hk = L.U[5 * k + 4];
-                const double lo = S.h_lo - hk, hi = S.h_hi - hk;
+                const double lo = h_lo - hk, hi = h_hi - hk;
                 const bool clamped = (dff[4] < lo) || (dff[4] > hi);
                 if (clamped) {
                     const double hc = fmin(fmax(dff[4], lo), hi);
@@ -574,7 +659,10 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         ldl_solve(kc, 5);
                     }
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) L.K[75 * k + 15 * i + lane] = kc[i];
+                    for (int i = 0; i < 5; ++i) {
+                        L.K[15 * i + lane] = kc[i];
+                        Kg[(int64_t)kKg * k + 16 * i + lane] = kc[i];
+                    }
                 }
                 if (lane == 0) {
 #pragma unroll
@@ -586,7 +674,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     const int r = e / 15, c = e - 15 * r;
                     double acc = L.Qux[e];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = fma(q[r][i], L.K[75 * k + 15 * i + c], acc);
+                    for (int i = 0; i < 5; ++i) acc = fma(L.Quu[5 * r + i], L.K[15 * i + c], acc);  // (q[r][i] with a per-lane r would push q into scratch memory)
                     L.S[e] = acc;
                 }
                 double m5[5];
@@ -604,8 +692,8 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     double acc = L.Qxx[e];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        acc = fma(L.K[75 * k + 15 * i + r], L.S[15 * i + c], acc);
-                        acc = fma(L.Qux[15 * i + r], L.K[75 * k + 15 * i + c], acc);
+                        acc = fma(L.K[15 * i + r], L.S[15 * i + c], acc);
+                        acc = fma(L.Qux[15 * i + r], L.K[15 * i + c], acc);
                     }
                     L.T[e] = acc;
                 }
@@ -613,7 +701,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     double acc = L.Qx[lane];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        acc = fma(L.K[75 * k + 15 * i + lane], m5[i], acc);
+                        acc = fma(L.K[15 * i + lane], m5[i], acc);
                         acc = fma(L.Qux[15 * i + lane], dff[i], acc);
                     }
                     L.pv[lane] = acc;
@@ -626,47 +714,60 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 wave_lds_sync();
             }
             if (!pd_ok) {
-                mu = fmin(mu * 10.0, S.mu_max);
-                if (mu >= S.mu_max) {
+                mu = fmin(mu * 10.0, mu_max);
+                if (mu >= mu_max) {
                     stalled = true;
                     break;
                 }
                 continue;
             }
 
-            // ---- forward: one closed-loop roll-out per step length, lane a tries alpha = 2^-a ----
+            QLN_TICK(tk_sweep);
+            __threadfence();  // the gains written during the sweep are read back by the roll-out lanes
+            // ---- forward: one closed-loop roll-out per step length, lane a tries alpha = 2^-a and keeps its
+            //      trajectory in the scratch (Z layout), so that the accepted one need not be rolled out again ----
             double J_try = INFINITY;
-            const double alpha = (lane < kAlphas) ? ldexp(1.0, -lane) : 0.0;
             if (lane < kAlphas) {
+                const double alpha = ldexp(1.0, -lane);
+                double* __restrict__ tz = traj + (int64_t)lane * 20 * N;
                 double x[15], u[5], xn[15];
                 double J = 0.0;
 #pragma unroll
                 for (int i = 0; i < 15; ++i) x[i] = L.X[i];
                 for (int k = 0; k < N - 1; ++k) {
+                    double kg[5][16];
+                    {
+                        const double2* __restrict__ kp = reinterpret_cast<const double2*>(Kg + (int64_t)kKg * k);
+#pragma unroll
+                        for (int j = 0; j < 5; ++j)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const double2 v = kp[8 * j + i];
+                                kg[j][2 * i] = v.x;
+                                kg[j][2 * i + 1] = v.y;
+                            }
+                    }
 #pragma unroll
                     for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * L.D[5 * k + j];
 #pragma unroll
                     for (int i = 0; i < 15; ++i) {
                         const double dx = x[i] - L.X[15 * k + i];
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) u[j] = fma(L.K[75 * k + 15 * j + i], dx, u[j]);
+                        for (int j = 0; j < 5; ++j) u[j] = fma(kg[j][i], dx, u[j]);
                     }
-                    u[4] = fmin(fmax(u[4], S.h_lo), S.h_hi);
-                    const double w = S.exact_h ? u[4] : L.kn[kKn * k + KN_W];
+                    u[4] = fmin(fmax(u[4], h_lo), h_hi);
+                    const double w = exact_h ? u[4] : L.kn[kKn * k + KN_W];
                     StageIn I = stage_in(k, rho, w);
                     StageOut o;
                     stage_eval(I, x, u, o);
                     J += o.val;
-                    if (lane == 0) {
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) L.Ut[5 * k + j] = u[j];
-                    }
+                    for (int j = 0; j < 5; ++j) tz[20 * k + 15 + j] = u[j];
                     step_forward(P, k, kt, im, Ib, x, u, xn);
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) x[i] = xn[i];
-                    if (lane == 0) {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) L.Xt[15 * (k + 1) + i] = xn[i];
+                    for (int i = 0; i < 15; ++i) {
+                        x[i] = xn[i];
+                        tz[20 * (k + 1) + i] = xn[i];
                     }
                 }
                 {
@@ -678,6 +779,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 }
                 J_try = J;
             }
+            QLN_TICK(tk_roll);
             // the best of the sixteen candidates, if any lowers the cost (all were computed anyway: one lane each)
             double J_best = ((lane < kAlphas) && (J_try == J_try) && (J_try < J_cur)) ? J_try : INFINITY;
             int a_star = lane;
@@ -690,10 +792,9 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     a_star = ao;
                 }
             }
-            wave_lds_sync();
             if (!(J_best < J_cur)) {  // no step length gives descent: more regularisation
-                mu = fmin(mu * 10.0, S.mu_max);
-                if (mu >= S.mu_max) {
+                mu = fmin(mu * 10.0, mu_max);
+                if (mu >= mu_max) {
                     stalled = true;
                     break;
                 }
@@ -701,50 +802,27 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             }
             const double J_new = J_best;
             last_alpha = ldexp(1.0, -a_star);
-            if (a_star != 0) {
-                // the accepted roll-out again, kept this time (every lane redundantly, lane 0 writes)
-                double x[15], u[5], xn[15];
-#pragma unroll
-                for (int i = 0; i < 15; ++i) x[i] = L.X[i];
-                for (int k = 0; k < N - 1; ++k) {
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + last_alpha * L.D[5 * k + j];
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) {
-                        const double dx = x[i] - L.X[15 * k + i];
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) u[j] = fma(L.K[75 * k + 15 * j + i], dx, u[j]);
-                    }
-                    u[4] = fmin(fmax(u[4], S.h_lo), S.h_hi);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) L.Ut[5 * k + j] = u[j];
-                    }
-                    step_forward(P, k, kt, im, Ib, x, u, xn);
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) x[i] = xn[i];
-                    if (lane == 0) {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) L.Xt[15 * (k + 1) + i] = xn[i];
-                    }
+            // accept: lane a_star's roll-out becomes the current trajectory (x_1 = x0 stays)
+            __threadfence();
+            wave_lds_sync();
+            {
+                const double* __restrict__ tz = traj + (int64_t)a_star * 20 * N;
+                for (int i = 15 + lane; i < 20 * (N - 1) + 15; i += kWave) {
+                    const int k = i / 20, j = i - 20 * k;
+                    const double v = __builtin_nontemporal_load(tz + i);
+                    if (j < 15) L.X[15 * k + j] = v;
+                    else L.U[5 * k + (j - 15)] = v;
                 }
             }
             wave_lds_sync();
-            {  // accept: the trial trajectory becomes the current one
-                double* t = L.X;
-                L.X = L.Xt;
-                L.Xt = t;
-                t = L.U;
-                L.U = L.Ut;
-                L.Ut = t;
-            }
-            mu = fmax(mu / 3.0, S.mu_min);
+            QLN_TICK(tk_accept);
+            mu = fmax(mu / 3.0, mu_min);
             const double dJ = J_cur - J_new;
-            if (dJ < S.inner_tol * (1.0 + fabs(J_new))) break;
+            if (dJ < inner_tol * (1.0 + fabs(J_new))) break;
         }
         // ---- outer: violation, stop test, multipliers, penalty ----
-        refresh(J_cur, viol);
-        if (viol <= S.tol) {
+        refresh(rho, J_cur, viol);
+        if (viol <= tol) {
             status = 0;
             ++outer;
             break;
@@ -759,9 +837,9 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
         if (lane < 14) L.leq[lane] += rho * (L.X[15 * (N - 1) + lane] - xf[lane]);
         if (lane == 14) L.leq[14] = L.kn[kKn * (N - 2) + KN_TFC];
         wave_lds_sync();
-        if (viol > 0.25 * prev_viol) rho = fmin(rho * S.rho_factor, S.rho_max);
+        if (viol > 0.25 * prev_viol) rho = fmin(rho * rho_factor, rho_max);
         prev_viol = viol;
-        if (stalled && rho >= S.rho_max) status = 2;
+        if (stalled && rho >= rho_max) status = 2;
     }
 
     // ---- write the solution (states of the roll-out: their dynamics rows are exactly zero) and the report ----
@@ -795,7 +873,12 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             o[7] = last_alpha;
             o[8] = hs;
             o[9] = mu;
-            for (int i = 10; i < 16; ++i) o[i] = 0.0;
+            o[10] = (double)tk_refresh;
+            o[11] = (double)tk_blocks;
+            o[12] = (double)tk_sweep;
+            o[13] = (double)tk_roll;
+            o[14] = (double)tk_accept;
+            o[15] = 0.0;
         }
     }
 }

@@ -102,4 +102,4 @@ def test_solve_is_deterministic_and_independent_of_batch_position():
     Z1, info1 = one.solve(one.initial_guess(), max_outer=6)
     torch.cuda.synchronize()
     assert torch.equal(Z.view(9, -1)[4], Z1.view(1, -1)[0])
-    assert torch.equal(info[4], info1[0])
+    assert torch.equal(info[4][:10], info1[0][:10])  # (entries 10-14 are phase timers)
