@@ -44,8 +44,12 @@ for line in open("$OUT/pmc_summary.txt"):
 # (MI355X_MICROARCH.md HBM section; re-calibrated here with bench/store_ceiling.hip: profiles/calibration_*.txt);
 # WRITE_SIZE (KiB) is exact.
 fetch=2*vals["FETCH_SIZE"]*1024; write=vals["WRITE_SIZE"]*1024
+import sys
+sys.path.insert(0, "$R")
+import bench
 json.dump({"$KEY":{"hbm_bytes_per_launch":fetch+write,"fetch_bytes_corrected":fetch,"write_bytes":write,
   "FETCH_SIZE_KiB_raw":vals["FETCH_SIZE"],"WRITE_SIZE_KiB_raw":vals["WRITE_SIZE"],
+  "build_id":bench.kernel_build_id(),"profile":"profiles/${TAG}_pmc_summary_$KEY.txt",
   "note":"per launch of k_constraint_jacobian; fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024"}},
   open("$OUT/traffic.json","w"),indent=1)
 print(open("$OUT/traffic.json").read())

@@ -145,6 +145,11 @@ int qln_eval_constraint(qln_handle* h, const double* Z, double* c);             
 int qln_eval_constraint_jacobian(qln_handle* h, const double* Z, double* vals, uint32_t flags); /* :212-291 */
 /* The fused hot path: eval_c! and jac_c! of every knot of every problem in one launch. */
 int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags);
+/* Everything an NLP iteration asks of the evaluator from ONE read of Z: f = eval_f, grad = grad_f!, c = eval_c!,
+ * vals = jac_c! (src/costs.jl:6-34, src/constraints.jl:145-158, 212-291) in a single launch -- the wave that has a
+ * problem's slice of Z in LDS for the constraint rows also forms the objective terms and the gradient from it.  Same
+ * layouts and the same bits as the separate entry points.  Needs a cost table. */
+int qln_eval_all(qln_handle* h, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags);
 int qln_jacobian_init_constants(qln_handle* h, double* vals);
 /* Products with the constraint Jacobian of jac_c! (src/constraints.jl:212-291) at Z, for the caller side of the path
  * (solver iterations on the GPU).  The Jacobian is not read from memory: every step block is re-derived

@@ -522,6 +522,16 @@ int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
     return QLN_OK;
 }
 
+int qln_eval_all(qln_handle* h, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
+    if (!Z || !f || !grad || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_all: null pointer");
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_eval_all(h->p, Z, f, grad, c, vals, flags & QLN_JAC_WRITE_CONSTANTS, h->stream));
+    return QLN_OK;
+}
+
 int qln_jacobian_init_constants(qln_handle* h, double* vals) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = check_vals(vals)) return rc;

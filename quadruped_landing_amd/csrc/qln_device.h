@@ -126,6 +126,8 @@ constexpr uint32_t kLaunchSplit = 2u;
 // Fused eval_c! + jac_c! over problems [b_begin, b_begin + nb).  c or vals may be null.
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,
                                       double* vals, uint32_t flags, hipStream_t stream);
+hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags,
+                           hipStream_t stream);
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream);
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream);
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream);

@@ -117,6 +117,55 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Objective (src/costs.jl:6-16).  One knot's term with the reference's operation order: the left-to-right sums of
+// 0.5 x'Qx, q'x, 0.5 u'Ru, r'u over a knot's entries (src/quadratic_cost.jl:44-52; Q, R diagonal), then
+// hk * ((((a + b) + c) + d) + const) -- so that the value rounds like eval_f.  z: the knot's 20 (terminal: 15) entries
+// of Z in LDS; rec: its 41-double cost record in global memory (all 41 loads in flight before the first use).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double objective_term(const double* z, const double* __restrict__ rec, bool stage) {
+    double D[20], d[20], zz[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        D[i] = rec[i];
+        d[i] = rec[20 + i];
+    }
+    const double c40 = rec[40];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) zz[i] = z[(i < 15 || stage) ? i : 14];
+    double a = (0.5 * (D[0] * zz[0])) * zz[0], bb = d[0] * zz[0];
+#pragma unroll
+    for (int i = 1; i < 15; ++i) {
+        a = a + (0.5 * (D[i] * zz[i])) * zz[i];
+        bb = bb + d[i] * zz[i];
+    }
+    double cc = (0.5 * (D[15] * zz[15])) * zz[15], dd = d[15] * zz[15];
+#pragma unroll
+    for (int i = 16; i < 20; ++i) {
+        cc = cc + (0.5 * (D[i] * zz[i])) * zz[i];
+        dd = dd + d[i] * zz[i];
+    }
+    return stage ? zz[19] * ((((a + bb) + cc) + dd) + c40) : (a + bb) + c40;
+}
+
+// J <- J + term_0 + term_1 + ... in knot order (src/costs.jl:9-15): the wave's terms go through LDS, every lane adds
+// them in the same order (lanes past the last knot hold 0.0, and J + 0.0 == J).
+__device__ __forceinline__ double add_terms_in_order(double J, double term, double* s_term, int lane) {
+    wave_lds_sync();
+    s_term[lane] = term;
+    wave_lds_sync();
+    // sixteen at a time: the loads of a batch are in flight together, and 32 registers hold them instead of 128
+#pragma unroll
+    for (int g = 0; g < kWave; g += 16) {
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = s_term[g + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) J += t[i];
+    }
+    return J;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused constraint + Jacobian kernel.
 // ---------------------------------------------------------------------------------------------
 // T  = knots assembled per LDS tile (tile = T*2400 B, the only LDS the kernel uses)
@@ -127,10 +176,14 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
 // SPLIT = small batches: one workgroup per CHUNK of KC knots instead of per problem, so that a batch with fewer
 //         problems than the chip has SIMDs still fills it (the launch is then as long as one chunk, not one problem)
 // STREAM = non-temporal stores for the outputs (large batches)
-template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false, bool SPLIT = false, bool STREAM = true>
+// WITH_F = the objective and its gradient as well (qln_eval_all): eval_f and grad_f! out of the same staged slice of Z
+template <int T, int KC, int W, bool WITH_C, bool WITH_J, bool NNZ = false, bool SPLIT = false, bool STREAM = true,
+          bool WITH_F = false>
 __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P, int32_t b_begin, int32_t nb,
                                                               const double* __restrict__ Z, double* __restrict__ C,
-                                                              double* __restrict__ V, uint32_t flags) {
+                                                              double* __restrict__ V, uint32_t flags,
+                                                              double* __restrict__ F = nullptr, double* __restrict__ G = nullptr) {
+    static_assert(!WITH_F || (!SPLIT && WITH_C), "the objective rides on the per-problem launch that also stages the value phase");
     // LDS: one tile of T dense step blocks.  Before the Jacobian phase of a chunk the same bytes
     // hold the staged Z slice (20*64+15 doubles at offset 0) and, behind it, the chunk's dynamics
     // residuals (64*15 doubles at offset kCStage).
@@ -140,7 +193,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     // structural format: up to 71 values per knot of the chunk, +1 so that the LDS image can start at the parity of
     // its global offset (16-byte pieces then line up on both sides)
     constexpr int kTile = NNZ ? ((KC * 71 + 2) & ~1) : T * kBlk;
-    static_assert(kTile >= kCStage + KC * 15, "Z slice + residual stage must fit in the tile they alias");
+    static_assert(kTile >= kCStage + KC * 15 + (WITH_F ? kWave : 0), "Z slice + residual stage (+ objective terms) must fit in the tile they alias");
     static_assert(kTile >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
     __shared__ double2 s_j2[kTile / 2];
     double* const s_j = reinterpret_cast<double*>(s_j2);
@@ -196,6 +249,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     const bool init1 = (im == 1);  // foot 1 touches first: contact-init row is y1, contact-other is y2
     // length of the step-block section of vals
     const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
+    double J_obj = 0.0;  // WITH_F: eval_f accumulated over the chunks, in knot order
 
     if (WITH_J && (flags & 1u) && kc_begin == 0) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
@@ -329,6 +383,39 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                         if constexpr (STREAM) __builtin_nontemporal_store(cr[it], &dst[i]);  // streamed like the blocks (-1 %)
                         else dst[i] = cr[it];
                     }
+                }
+            }
+        }
+
+        // ============================== objective + gradient (eval_f, grad_f!) ==================
+        if constexpr (WITH_F) {
+            const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+            // eval_f (src/costs.jl:6-16): lane = knot of the chunk, the terminal knot x_N rides on lane nk of the last chunk
+            // (a second pass when that chunk is full); terms are added in knot order
+            {
+                const bool own = valid || (last_chunk && lane == nk);
+                const int kk = own ? lane : 0;
+                const double term = objective_term(s_z + 20 * kk, cost + (int64_t)(kc0 + kk) * 41, valid);
+                J_obj = add_terms_in_order(J_obj, own ? term : 0.0, s_c + KC * 15, lane);
+                if (last_chunk && nk == kWave) {  // wave-uniform
+                    const double tn = objective_term(s_z + 20 * nk, cost + (int64_t)(N - 1) * 41, false);
+                    J_obj = J_obj + tn;
+                }
+            }
+            // grad_f! (src/costs.jl:23-34, no d(h l)/dh: quirk Q2): lane = entry of the staged slice, coalesced stores;
+            // the slice's last 15 entries are x_{k+1} of the next chunk, or x_N -- the terminal knot -- in the last one
+            {
+                double* __restrict__ Gb = G + (int64_t)b * P.z_stride + 20 * kc0;
+                const int ng = 20 * nk + (last_chunk ? 15 : 0);
+#pragma unroll
+                for (int it = 0; it < kStageIters; ++it) {
+                    const int e = min(it * kWave + lane, ng - 1);
+                    const int kk = e / 20, j = e - 20 * kk;
+                    const double* ck = cost + (int64_t)(kc0 + kk) * 41;
+                    const double lin = ck[j] * s_z[e] + ck[20 + j];
+                    const double hk = s_z[min(20 * kk + 19, nz - 1)];
+                    const double gv = (kk < nk) ? hk * lin : lin;
+                    if (it * kWave + lane < ng) Gb[e] = gv;
                 }
             }
         }
@@ -480,6 +567,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             }  // dense blocks
         }
     }
+    if constexpr (WITH_F) {
+        if (lane == 0) F[b] = J_obj;
+    }
     QLN_STAMP(15);
 }
 
@@ -509,84 +599,36 @@ __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, dou
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Objective (src/costs.jl:6-16) -- one wavefront per problem, lane per knot, and the reference's
-// sequential left-to-right sum over knots done by lane 0 so the value rounds like eval_f.
-// ---------------------------------------------------------------------------------------------
+// Objective (src/costs.jl:6-16): objective_term / add_terms_in_order are defined above the fused kernel, which uses them too.
+// One wavefront per problem, 64 knots per pass: the pass's slice of Z is read with coalesced loads (all in flight before
+// the first wait) into LDS -- the only LDS the kernel uses, 10 KB, so that a CU holds 14 waves -- and lane = knot
+// forms its term straight from there.
 __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
-    // Lane = entry of Z for the products (coalesced reads of Z and of the [k][41] cost records), lane = knot for
-    // the reference's left-to-right sums (src/quadratic_cost.jl:44-52), lane 0 for the sequential sum over knots
-    // (src/costs.jl:9-15): every floating-point operation and its order is the reference's, so f is bit-identical.
-    // A pass covers 64 knots (1280 entries of Z = 20 loads per lane, all in flight before the first wait).
-    constexpr int kKnots = kWave;                    // knots per pass
-    constexpr int kIters = kKnots * 20 / kWave;      // entries per lane and pass
-    __shared__ double s_quad[kKnots * 20];           // (0.5 * (D_i * z_i)) * z_i
-    __shared__ double s_lin[kKnots * 20];            // d_i * z_i
-    __shared__ double s_h[kKnots];                   // h_k = u_k[5]
-    __shared__ double s_term[kKnots];
+    constexpr int kSlice = kWave * 20;
+    __shared__ double s_z[kSlice];
+    __shared__ double s_term[kWave];
     const int lane = threadIdx.x;
     const int b = xcd_contiguous_index(blockIdx.x, P.B);
     if (b >= P.B) return;
     const int N = P.N;
+    const int n_nlp = 20 * N - 5;
     const double* __restrict__ Zb = Z + (int64_t)b * P.z_stride;
     const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
     double J = 0.0;
-    for (int k0 = 0; k0 < N; k0 += kKnots) {
-        const int nk = min(kKnots, N - k0);
-        const int ne = min(20 * nk, 20 * N - 5 - 20 * k0);  // entries of Z in this pass (x_N has no controls)
-        double z[kIters], D[kIters], d[kIters];
+    for (int k0 = 0; k0 < N; k0 += kWave) {
+        const int nk = min(kWave, N - k0);
+        const int ne = min(20 * nk, n_nlp - 20 * k0);  // entries of Z in this pass (x_N has no controls)
+        double zr[20];
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int e = min(it * kWave + lane, ne - 1);   // clamped, not predicated
-            const int kk = e / 20, j = e - 20 * kk;
-            const double* ck = cost + (int64_t)(k0 + kk) * 41;
-            z[it] = Zb[20 * k0 + e];
-            D[it] = ck[j];                                   // Q or R slot j
-            d[it] = ck[20 + j];                              // q or r slot j
-        }
-        const double ck40 = cost[(int64_t)(k0 + min(lane, nk - 1)) * 41 + 40];
+        for (int it = 0; it < 20; ++it) zr[it] = Zb[20 * k0 + min(it * kWave + lane, ne - 1)];  // clamped, not predicated
         wave_lds_sync();  // the previous pass's readers are done
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int e = it * kWave + lane;
-            s_quad[e] = (0.5 * (D[it] * z[it])) * z[it];
-            s_lin[e] = d[it] * z[it];
-            const int kk = e / 20;
-            if (e - 20 * kk == 19 && e < ne) s_h[kk] = z[it];
-        }
+        for (int it = 0; it < 20; ++it) s_z[it * kWave + lane] = zr[it];
         wave_lds_sync();
-        {
-            const int kl = min(lane, nk - 1);
-            const int k = k0 + kl;
-            const double* q = s_quad + 20 * kl;
-            const double* l = s_lin + 20 * kl;
-            double a = q[0], bb = l[0];
-#pragma unroll
-            for (int i = 1; i < 15; ++i) {
-                a = a + q[i];
-                bb = bb + l[i];
-            }
-            double term;
-            if (k < N - 1) {
-                double cc = q[15], dd = l[15];
-#pragma unroll
-                for (int i = 16; i < 20; ++i) {
-                    cc = cc + q[i];
-                    dd = dd + l[i];
-                }
-                term = s_h[kl] * ((((a + bb) + cc) + dd) + ck40);  // hk * stagecost
-            } else {
-                term = (a + bb) + ck40;                             // termcost
-            }
-            s_term[lane] = (lane < nk) ? term : 0.0;
-        }
-        wave_lds_sync();
-        // J += term_k for k in order; the lanes past nk hold 0.0 and J + 0.0 == J
-        double t[kKnots];
-#pragma unroll
-        for (int i = 0; i < kKnots; ++i) t[i] = s_term[i];
-#pragma unroll
-        for (int i = 0; i < kKnots; ++i) J += t[i];
+        const int kl = min(lane, nk - 1);
+        const int k = k0 + kl;
+        const double term = objective_term(s_z + 20 * kl, cost + (int64_t)k * 41, k < N - 1);
+        J = add_terms_in_order(J, (lane < nk) ? term : 0.0, s_term, lane);
     }
     if (lane == 0) F[b] = J;
 }
@@ -838,6 +880,24 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
     // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
     if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
     return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+}
+
+// f, grad, c and the Jacobian values of the whole batch from ONE read of Z (qln_eval_all)
+hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags,
+                           hipStream_t stream) {
+    const int nb = p.B;
+    dim3 grid(xcd_grid(nb)), block(kWave);
+    const bool structural = p.jac_format == QLN_JAC_FORMAT_STRUCTURAL;
+    const bool stream_out = (int64_t)nb * (p.N - 1) * (structural ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
+    flags &= QLN_JAC_WRITE_CONSTANTS;
+    if (structural) {
+        if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+        else hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+    } else {
+        if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+        else hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream) {

@@ -374,6 +374,19 @@ class HybridNLP:
             self._check(vals, self.dims.j_total, "vals"), flags))
         return c, vals
 
+    def eval_all(self, Z, f=None, grad=None, c=None, vals=None, write_constants: bool = True):
+        """f, grad_f, c and the Jacobian values from one read of Z, in one launch (qln_eval_all)."""
+        f = self.new_f() if f is None else f
+        grad = self.new_Z() if grad is None else grad
+        c = self.new_c() if c is None else c
+        vals = self.new_vals() if vals is None else vals
+        flags = _lib.QLN_JAC_WRITE_CONSTANTS if write_constants else 0
+        _lib.check(_lib.lib().qln_eval_all(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(f, self.B, "f"),
+            self._check(grad, self.dims.z_total, "grad"), self._check(c, self.dims.c_total, "c"),
+            self._check(vals, self.dims.j_total, "vals"), flags))
+        return f, grad, c, vals
+
     def init_jacobian_constants(self, vals):
         _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
         return vals

@@ -467,3 +467,29 @@ def test_host_pointer_mode_both_paths(B):
         nlp.jac_c_dense_host(batch.Z[B - 1], D, B - 1)
         r, cidx = nlp.jacobian_structure(B - 1)
         assert np.array_equal(D[r, cidx], nlp.split_vals(vd, B - 1))
+
+
+@pytest.mark.parametrize("B,N,ragged,fmt", [(64, 40, False, "dense_blocks"), (33, 61, False, "structural"), (29, 80, True, "dense_blocks"),
+                                            (17, 130, True, "structural"), (5, 64, False, "dense_blocks"), (3, 65, False, "dense_blocks"),
+                                            (4, 2, False, "dense_blocks")])
+def test_eval_all_gives_the_bits_of_the_separate_entry_points(B, N, ragged, fmt):
+    """qln_eval_all: f, grad_f, c and the Jacobian values out of one read of Z in one launch are bit for bit what
+    qln_eval_objective / _gradient / qln_eval_constraint_and_jacobian give (which are held to the oracle above) --
+    incl. horizons of exactly one chunk (N - 1 = 64: the terminal knot has no lane left), more than one chunk, N = 2."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(B, N, min(14, N), 1, seed=B + N, ragged=ragged)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf, jac_format=fmt)
+    Z = nlp.upload_Z(batch.Z)
+    nan = float("nan")
+    mk = lambda n: torch.full((n,), nan, dtype=torch.float64, device="cuda")
+    f, g, c, v = nlp.eval_all(Z, mk(B), mk(nlp.dims.z_total), mk(nlp.dims.c_total), mk(nlp.dims.j_total))
+    c1, v1 = nlp.eval_c_and_jac(Z, mk(nlp.dims.c_total), mk(nlp.dims.j_total))
+    f1, g1 = nlp.eval_f(Z), nlp.grad_f(Z, mk(nlp.dims.z_total))
+    torch.cuda.synchronize()
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert eq(c, c1) and eq(v, v1) and eq(f, f1) and eq(g, g1)
+    assert not torch.isnan(f).any()
+    ref = oracle_batch(batch, nlp, want_c=False, want_j=False, want_f=True, want_grad=True)
+    assert np.array_equal(f.cpu().numpy(), ref["f"])  # and the objective is bit-identical to the oracle
