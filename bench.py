@@ -56,18 +56,37 @@ def strict_bytes(N, k_trans):
     return 8 * (20 * N - 5) + 8 * (18 * N - kt + 16) + 8 * (nnz + N)
 
 
-def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks"):
+def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks", host_data=False):
     import torch
-    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+    from quadruped_landing_amd import HybridNLP, PlanarQuadruped, problem_gen as PG
 
     w = WORKLOADS[workload]
-    # per-problem cost tables (config 4: 1.7 GB) are built on the device (qln_set_lqr_cost), not uploaded
-    batch = PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=seed, ragged=w["ragged"], build_obj=not w["ragged"])
-    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
-                    device=device, stream=torch.cuda.current_stream(), jac_format=jac_format)
-    if batch.obj is None:
-        nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=True)
-    Z = nlp.upload_Z(batch.Z)
+    if w["ragged"] or host_data:
+        # host generator (numpy): the ragged workload's per-problem k_trans / init_mode draws have no closed-form position
+        # in the PCG64 stream.  Per-problem cost tables (config 4: 1.7 GB) are built on the device, not uploaded.
+        batch = PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=seed, ragged=w["ragged"], build_obj=not w["ragged"])
+        nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                        device=device, stream=torch.cuda.current_stream(), jac_format=jac_format)
+        if batch.obj is None:
+            nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=True)
+        Z = nlp.upload_Z(batch.Z)
+        build.last_data = "host generator (problem_gen.make_batch), uploaded"
+    else:
+        # the whole synthetic workload is generated where it is used: drop states with numpy's own
+        # PCG64 stream positions (x0 bit-identical to make_batch(seed)), the LQR cost records, the notebook's initial
+        # guess and its N(0, 0.05^2) perturbation -- nothing but the descriptors is uploaded
+        model = PlanarQuadruped()
+        B, N = w["B"], w["N"]
+        kt = np.full(B, w["k_trans"], dtype=np.int32)
+        im = np.full(B, 1, dtype=np.int32)
+        xf = np.tile(PG.terminal_state(model), (B, 1))
+        nlp = HybridNLP(model, None, im, kt, N, np.zeros((B, 15)), xf, device=device, stream=torch.cuda.current_stream(),
+                        jac_format=jac_format)
+        x0 = nlp.sample_drop_states(PG.drop_state_sampler(seed, model))
+        nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=False)
+        Z = nlp.perturb_point(nlp.initial_guess(), PG.drop_state_sampler(seed, model, stream_offset=4 * B), sigma=0.05)
+        batch = PG.LandingBatch(model, N, kt, im, x0, xf, None, None)  # Z stays on the device (cpu_baseline fetches it)
+        build.last_data = "generated on the device (qln_sample_drop_states / qln_set_lqr_cost / qln_initial_guess / qln_perturb_point)"
     c = nlp.new_c()
     # setup: the long-lived output buffer is allocated once; among `placement_trials` candidate allocations the one
     # whose physical placement sustains the best store bandwidth is kept (HybridNLP.new_vals_placed)
@@ -80,17 +99,21 @@ def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks")
     return batch, nlp, Z, c, vals
 
 
-def cpu_baseline(batch, nlp, budget_s=12.0):
+def cpu_baseline(batch, nlp, Z_dev, budget_s=12.0):
     """Oracle (C restatement of the reference algorithm, 1 thread) on a bounded sample of the SAME
     workload.  Reported baseline, not the target."""
     from tests.helpers import oracle_model
     from oracle import oracle as O
 
+    if batch.Z is None:  # device-generated workload: the oracle gets the very point the GPU evaluated
+        batch.Z = Z_dev.cpu().numpy().reshape(batch.B, -1)[:, : nlp.n_nlp]
+
     def run(nb, nthreads):
         Zs = np.zeros((nb, nlp.z_stride))
         Zs[:, : nlp.n_nlp] = batch.Z[:nb]
-        if batch.obj is None:  # device-built per-problem tables: fetch the sample's records back for the oracle
-            obj = nlp.get_cost()[:nb]
+        if batch.obj is None:  # device-built cost records: fetch the sample's back for the oracle
+            obj = nlp.get_cost()
+            obj = obj if obj.ndim == 2 else obj[:nb]
         else:
             obj = batch.obj if batch.obj.ndim == 2 else batch.obj[:nb]
         c_off = nlp.c_off[:nb] - nlp.c_off[0]
@@ -159,6 +182,9 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=8,
                     help="1 = the Jacobian buffer is a plain allocation; > 1 = it is placed across two 32-GiB regions of device "
                          "memory at setup (HybridNLP.new_vals_placed), falling back to this many timed candidate allocations")
+    ap.add_argument("--host-data", action="store_true",
+                    help="generate the synthetic workload on the host with numpy and upload it (the default for the uniform "
+                         "workloads is the device-side generator; the ragged workload is always generated on the host)")
     ap.add_argument("--mode", default="auto", choices=["auto", "ranks", "single-process"],
                     help="how N GPUs are driven: 'ranks' = one process per GPU (a launcher set WORLD_SIZE/RANK/LOCAL_RANK: the "
                          "driver's torch.distributed.run line), RCCL through qln_comm_*; 'single-process' = this process "
@@ -311,7 +337,8 @@ def run_ranks(args):
 
     # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
     batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
-                                   jac_format=args.jac_format)
+                                   jac_format=args.jac_format, host_data=args.host_data)
+    data_how = build.last_data
     placement_ms = list(build.last_trials)
     placement_how = build.last_placement
     f, viol = nlp.new_f(), nlp.new_f()
@@ -362,7 +389,7 @@ def run_ranks(args):
     if rank == 0:
         out = base_record(args, batch.B * batch.N * world * K / elapsed, world, elapsed, batch.B, batch.N, nlp.z_stride,
                           {"driver": "one process per GPU" + (", RCCL through qln_comm_* (include/qln_multi.h)" if comm is not None else ""),
-                           "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms})
+                           "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms, "workload_data": data_how})
         out["roofline"] = roofline_record(args, batch, ms_each)
         if comm is not None:
             assert f_all.numel() == batch.B * world and viol_all.numel() == batch.B * world
@@ -391,9 +418,26 @@ def run_ranks(args):
                                                    "roofline_frac": alg2 / (float(np.mean(ms2)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                    "note": "BASELINE.json configs[1] (0-based): one wave per problem = 4 waves per CU, "
                                                            "a single round: launch-latency regime"}
-            del b2, n2, Z2, c2, v2
+            # the caller side of the path on the same configuration: every problem of configs[1] SOLVED
+            # from the notebook's initial-guess rule by qln_solve, judged by the evaluator
+            Zs = n2.initial_guess()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            Zs, sinfo = n2.solve(Zs)
+            torch.cuda.synchronize()
+            ts = time.perf_counter() - ts
+            sviol = n2.constraint_violation(n2.eval_c(Zs)).cpu().numpy()
+            si = sinfo.cpu().numpy()
+            out["other"]["solve_config2_B1024_N40"] = {
+                "solved_problems_per_s": float((sviol <= 1e-6 * 1.0001).sum()) / ts, "wall_ms": ts * 1e3,
+                "problems": int(b2.B), "solved_to_1e-6": int((sviol <= 1e-6 * 1.0001).sum()),
+                "ilqr_iterations_median": float(np.median(si[:, 1])), "ilqr_iterations_max": float(si[:, 1].max()),
+                "violation_max": float(sviol.max()), "objective_median": float(np.median(si[:, 2])),
+                "note": "qln_solve (augmented-Lagrangian iLQR, one wave per problem) from qln_initial_guess's Z0; violation = "
+                        "qln_constraint_violation of the returned Z (Ipopt's definition)"}
+            del b2, n2, Z2, c2, v2, Zs
         if world == 1 and not args.no_cpu_baseline:
-            one, allc = cpu_baseline(batch, nlp)
+            one, allc = cpu_baseline(batch, nlp, Z)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
     if comm is not None:

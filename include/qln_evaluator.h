@@ -220,6 +220,28 @@ int qln_constraint_violation(qln_handle* h, const double* c, double* viol /*[B]*
  * on the device in the handle's Z layout.  Needs k_trans >= 2 for every problem (the notebook divides by
  * k_trans - 1). */
 int qln_initial_guess(qln_handle* h, double* Z);
+/* The synthetic workload of SURVEY.md 8d generated on the device (8f-3): per-problem random drop states
+ *   theta0 ~ U(theta_deg) degrees, y2_0 ~ U(y2), vby0 = -sqrt(two_g * H) with H ~ U(drop_height), omega0 ~ U(omega),
+ * written into x0_template's entries 3, 7, 9, 10 (1-based; the notebook's xinit, src/main.ipynb:114-124) and mirrored for
+ * init_mode 2.  The uniform draws are those of numpy.random.default_rng(seed) (PCG64) consumed in the host recipe's
+ * order -- theta0[B], y2_0[B], H[B], omega0[B] starting `stream_offset` draws into the stream -- bit for bit: pcg_state /
+ * pcg_inc are numpy.random.PCG64(seed).state's 128-bit `state` and `inc` as {high, low} words.  Replaces the x0 the
+ * handle was created with. */
+typedef struct qln_drop_state_sampler {
+    uint64_t pcg_state[2], pcg_inc[2];
+    int64_t stream_offset;
+    double x0_template[15];
+    double theta_deg[2], y2[2], drop_height[2], omega[2];  /* {low, high} */
+    double two_g;                                          /* 2 * 9.81 in the recipe */
+} qln_drop_state_sampler;
+int qln_sample_drop_states(qln_handle* h, const qln_drop_state_sampler* s);
+/* Z <- Z + N(0, sigma^2) on every entry, step lengths h then clipped to [h_min, h_max] (redraw_h = 0) or redrawn
+ * U(h_min, h_max) (redraw_h != 0) -- the evaluation point of SURVEY.md 8d from qln_initial_guess's Z0.  The normal
+ * draws are Box-Muller on the sampler's stream from `stream_offset`: the recipe's distribution, not numpy's numbers. */
+int qln_perturb_point(qln_handle* h, const qln_drop_state_sampler* s, double* Z, double sigma, double h_min, double h_max,
+                      int redraw_h);
+/* the handle's current boundary states, copied to host arrays ([B][15] each; either may be NULL) */
+int qln_get_boundary_states(qln_handle* h, double* x0, double* xf);
 /* The notebook's objective built on the device: obj[k] = LQRCost(Q, R, Xref[k], Uref[k]), k < N, and
  * obj[N] = LQRCost(Qf, R*0, Xref[N], Uref[1]) (src/main.ipynb:158-161, src/quadratic_cost.jl:33-42) with Xref/Uref of
  * reference_trajectory(model, N, k_trans, xf, init_mode, dt) (src/ref_traj.jl:6-39).  Q, Qf: 15 diagonal entries,

@@ -80,6 +80,20 @@ class QlnSolveOptions(C.Structure):
     ]
 
 
+class QlnDropStateSampler(C.Structure):
+    _fields_ = [
+        ("pcg_state", C.c_uint64 * 2),
+        ("pcg_inc", C.c_uint64 * 2),
+        ("stream_offset", C.c_int64),
+        ("x0_template", C.c_double * 15),
+        ("theta_deg", C.c_double * 2),
+        ("y2", C.c_double * 2),
+        ("drop_height", C.c_double * 2),
+        ("omega", C.c_double * 2),
+        ("two_g", C.c_double),
+    ]
+
+
 SOLVE_INFO_STRIDE = 16
 
 
@@ -123,6 +137,9 @@ SIGNATURES = {
     "qln_solve_default_options": (C.c_int, [C.POINTER(QlnSolveOptions)]),
     "qln_solve": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
+    "qln_sample_drop_states": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler)]),
+    "qln_perturb_point": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler), _dp, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "qln_get_boundary_states": (C.c_int, [_vp, _dp, _dp]),
     "qln_set_lqr_cost": (C.c_int, [_vp, _dp, _dp, _dp, C.c_double, C.c_int]),
     "qln_get_cost": (C.c_int, [_vp, _dp, _i32p]),
     "qln_eval_objective_host": (C.c_int, [_vp, _dp, _dp]),

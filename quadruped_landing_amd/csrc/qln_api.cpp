@@ -643,6 +643,54 @@ int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt, double* in
     return QLN_OK;
 }
 
+static qln::DropStateSampler sampler_of(const qln_drop_state_sampler* s) {
+    qln::DropStateSampler d;
+    d.state_hi = s->pcg_state[0], d.state_lo = s->pcg_state[1];
+    d.inc_hi = s->pcg_inc[0], d.inc_lo = s->pcg_inc[1];
+    d.stream_offset = s->stream_offset;
+    std::memcpy(d.x0_template, s->x0_template, sizeof d.x0_template);
+    const double* r[4] = {s->theta_deg, s->y2, s->drop_height, s->omega};
+    for (int a = 0; a < 4; ++a) {
+        d.lo[a] = r[a][0];
+        d.range[a] = r[a][1] - r[a][0];  // numpy: low + (high - low) * u
+    }
+    d.deg2rad = M_PI / 180.0;  // numpy.deg2rad: x * (pi / 180)
+    d.two_g = s->two_g;
+    return d;
+}
+
+int qln_sample_drop_states(qln_handle* h, const qln_drop_state_sampler* s) {
+    if (int rc = check_handle(h)) return rc;
+    if (!s) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_sample_drop_states: null sampler");
+    if (s->stream_offset < 0) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_sample_drop_states: negative stream_offset");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_sample_drop_states(h->p, sampler_of(s), h->d_bnd, h->stream));
+    return QLN_OK;
+}
+
+int qln_perturb_point(qln_handle* h, const qln_drop_state_sampler* s, double* Z, double sigma, double h_min, double h_max,
+                      int redraw_h) {
+    if (int rc = check_handle(h)) return rc;
+    if (!s || !Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_perturb_point: null pointer");
+    if (s->stream_offset < 0 || !(sigma >= 0) || !(h_max >= h_min)) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_perturb_point: bad argument");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_perturb_point(h->p, sampler_of(s), Z, sigma, h_min, h_max, redraw_h, h->stream));
+    return QLN_OK;
+}
+
+int qln_get_boundary_states(qln_handle* h, double* x0, double* xf) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    std::vector<double> bnd((size_t)h->dims.B * 30);
+    QLN_HIP(hipStreamSynchronize(h->stream));
+    QLN_HIP(hipMemcpy(bnd.data(), h->d_bnd, bnd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int32_t b = 0; b < h->dims.B; ++b) {
+        if (x0) std::memcpy(x0 + (size_t)b * 15, &bnd[(size_t)b * 30], 15 * sizeof(double));
+        if (xf) std::memcpy(xf + (size_t)b * 15, &bnd[(size_t)b * 30 + 15], 15 * sizeof(double));
+    }
+    return QLN_OK;
+}
+
 int qln_initial_guess(qln_handle* h, double* Z) {
     if (int rc = check_handle(h)) return rc;
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");

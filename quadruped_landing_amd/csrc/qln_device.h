@@ -141,6 +141,17 @@ size_t gauss_newton_lds_bytes(int32_t N);
 hipError_t launch_gauss_newton_step(const BatchParams& p, const double* Z, const double* c, double* dZ, int max_iters,
                                     double rel_tol, const double* radius, const double* col_scale, double* info,
                                     hipStream_t stream);
+// device-side generator of the synthetic workload (qln_sampler_kernels.hip)
+struct DropStateSampler {
+    unsigned long long state_hi, state_lo, inc_hi, inc_lo;  // numpy.random.PCG64(seed).state
+    long long stream_offset;                                // draws of the stream consumed before this call
+    double x0_template[15];
+    double lo[4], range[4];                                 // theta0 [deg], y2_0, drop height H, omega0: low and high - low
+    double deg2rad, two_g;
+};
+hipError_t launch_sample_drop_states(const BatchParams& p, const DropStateSampler& s, double* bnd, hipStream_t stream);
+hipError_t launch_perturb_point(const BatchParams& p, const DropStateSampler& s, double* Z, double sigma, double h_lo, double h_hi,
+                                int redraw_h, hipStream_t stream);
 // batched augmented-Lagrangian iLQR solve of the reference NLP (qln_ilqr_kernels.hip)
 struct SolveParams {
     int32_t max_outer, max_inner;

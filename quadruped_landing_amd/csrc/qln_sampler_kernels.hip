@@ -1,0 +1,136 @@
+// qln_sampler_kernels.hip -- the synthetic workload of SURVEY.md 8d generated where it is used: per-problem random drop
+// states around the notebook's initial condition (src/main.ipynb:114-124) and the noisy evaluation point, on the device.
+//
+// The host recipe (quadruped_landing_amd/problem_gen.py) draws with numpy.random.default_rng(seed): PCG64, a 128-bit
+// LCG with an XSL-RR output function, consumed in order -- theta0[B], y2_0[B], H[B], omega0[B], each
+// low + (high - low) * (next_uint64 >> 11) * 2^-53.  An LCG can be advanced by p steps in O(log p), so problem i
+// reads positions i, B + i, 2B + i, 3B + i of the SAME stream directly: the uniform draws -- and with them every x0 --
+// are bit-identical to the host generator's (tests/test_gpu_sampler.py).  The Gaussian noise of the evaluation point is
+// numpy's ziggurat on the host; here it is Box-Muller on the same kind of stream: the same distribution, not the same
+// numbers (documented: "distribution only").
+#include "qln_kernel_common.h"
+
+namespace qln {
+namespace {
+
+struct u128 {
+    unsigned long long hi, lo;
+};
+__device__ __forceinline__ u128 mul128(u128 a, u128 b) {  // mod 2^128
+    u128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi;
+    return r;
+}
+__device__ __forceinline__ u128 add128(u128 a, u128 b) {
+    u128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+}
+constexpr unsigned long long kMulHi = 0x2360ED051FC65DA4ull, kMulLo = 0x4385DF649FCCF645ull;  // PCG_DEFAULT_MULTIPLIER_128
+
+// state after `delta` steps of  s <- s * MULT + inc   (Brown, "Random number generation with arbitrary strides")
+__device__ __forceinline__ u128 pcg_advance(u128 state, u128 inc, unsigned long long delta) {
+    u128 acc_mult = {0ull, 1ull}, acc_plus = {0ull, 0ull};
+    u128 cur_mult = {kMulHi, kMulLo}, cur_plus = inc;
+    while (delta > 0) {
+        if (delta & 1ull) {
+            acc_mult = mul128(acc_mult, cur_mult);
+            acc_plus = add128(mul128(acc_plus, cur_mult), cur_plus);
+        }
+        const u128 one = {0ull, 1ull};
+        cur_plus = mul128(add128(cur_mult, one), cur_plus);
+        cur_mult = mul128(cur_mult, cur_mult);
+        delta >>= 1;
+    }
+    return add128(mul128(acc_mult, state), acc_plus);
+}
+__device__ __forceinline__ u128 pcg_step(u128 s, u128 inc) { return add128(mul128(s, u128{kMulHi, kMulLo}), inc); }
+// XSL-RR 128/64 output of a state (numpy steps first, then outputs)
+__device__ __forceinline__ unsigned long long pcg_output(u128 s) {
+    const unsigned long long x = s.hi ^ s.lo;
+    const unsigned rot = (unsigned)(s.hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+__device__ __forceinline__ double to_double(unsigned long long v) { return (double)(v >> 11) * (1.0 / 9007199254740992.0); }
+
+// x0 of every problem (src/main.ipynb:114-124 with SURVEY.md 8d's ranges): the template's entries 2 (theta0), 6 (y2_0),
+// 8 (vby0 = -sqrt(2 g H)) and 9 (omega0) are drawn, the feet are mirrored for init_mode 2.  One thread per problem.
+__global__ __launch_bounds__(256) void k_sample_drop_states(BatchParams P, DropStateSampler S, double* __restrict__ bnd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
+    const u128 st0 = {S.state_hi, S.state_lo}, inc = {S.inc_hi, S.inc_lo};
+    double u[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const unsigned long long p = (unsigned long long)S.stream_offset + (unsigned long long)a * (unsigned long long)P.B + (unsigned long long)i;
+        u[a] = to_double(pcg_output(pcg_advance(st0, inc, p + 1)));
+    }
+    double x[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) x[j] = S.x0_template[j];
+    x[2] = (S.lo[0] + S.range[0] * u[0]) * S.deg2rad;  // numpy.deg2rad(uniform(-40, -10))
+    x[6] = S.lo[1] + S.range[1] * u[1];
+    x[8] = -sqrt(S.two_g * (S.lo[2] + S.range[2] * u[2]));
+    x[9] = S.lo[3] + S.range[3] * u[3];
+    if (P.desc[i].init_mode == 2) {  // mirror the feet: foot 2 touches first
+        double t;
+        t = x[3], x[3] = x[5], x[5] = t;
+        t = x[4], x[4] = x[6], x[6] = t;
+        t = x[10], x[10] = x[12], x[12] = t;
+        t = x[11], x[11] = x[13], x[13] = t;
+    }
+    double* o = bnd + (int64_t)i * 30;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) o[j] = x[j];
+}
+
+// Z += N(0, sigma^2) on every entry, then the step lengths h clipped to [h_lo, h_hi] (uniform batches) or redrawn
+// U(h_lo, h_hi) (redraw_h: the ragged workload) -- SURVEY.md 8d.  Each thread owns 16 consecutive entries of the batch
+// and 32 consecutive positions of the stream (Box-Muller: two uniforms per normal).
+__global__ __launch_bounds__(256) void k_perturb_point(BatchParams P, DropStateSampler S, double* __restrict__ Z, double sigma,
+                                                      double h_lo, double h_hi, int redraw_h, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e0 = t * 16;
+    if (e0 >= total) return;
+    const int n_nlp = 20 * P.N - 5;
+    const u128 inc = {S.inc_hi, S.inc_lo};
+    u128 s = pcg_advance(u128{S.state_hi, S.state_lo}, inc, (unsigned long long)S.stream_offset + 2ull * (unsigned long long)e0);
+    for (int q = 0; q < 16 && e0 + q < total; ++q) {
+        s = pcg_step(s, inc);
+        const double u1 = to_double(pcg_output(s));
+        s = pcg_step(s, inc);
+        const double u2 = to_double(pcg_output(s));
+        const int64_t e = e0 + q;
+        const int64_t b = e / n_nlp;
+        const int i = (int)(e - b * n_nlp);
+        double* zp = Z + b * P.z_stride + i;
+        const bool is_h = (i % 20 == 19);
+        if (is_h && redraw_h) {
+            *zp = h_lo + (h_hi - h_lo) * u1;
+        } else {
+            const double g = sqrt(-2.0 * log(1.0 - u1)) * cospi(2.0 * u2);  // 1 - u1 in (0, 1]
+            const double v = *zp + sigma * g;
+            *zp = is_h ? fmin(fmax(v, h_lo), h_hi) : v;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_sample_drop_states(const BatchParams& p, const DropStateSampler& s, double* bnd, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sample_drop_states, dim3((p.B + 255) / 256), dim3(256), 0, stream, p, s, bnd);
+    return hipGetLastError();
+}
+
+hipError_t launch_perturb_point(const BatchParams& p, const DropStateSampler& s, double* Z, double sigma, double h_lo, double h_hi,
+                                int redraw_h, hipStream_t stream) {
+    const int64_t total = (int64_t)p.B * (20 * p.N - 5);
+    const int64_t threads = (total + 15) / 16;
+    hipLaunchKernelGGL(k_perturb_point, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, s, Z, sigma, h_lo, h_hi, redraw_h,
+                       total);
+    return hipGetLastError();
+}
+
+}  // namespace qln

@@ -458,6 +458,25 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_initial_guess(self._h, self._check(out, self.dims.z_total, "Z")))
         return out
 
+    def sample_drop_states(self, sampler):
+        """Redraw x0 of every problem on the device (qln_sample_drop_states; `sampler` from
+        problem_gen.drop_state_sampler): bit-identical to problem_gen.make_batch's host draws.  Updates self.x0."""
+        _lib.check(_lib.lib().qln_sample_drop_states(self._h, C.byref(sampler)))
+        self.x0, _ = self.boundary_states()
+        return self.x0
+
+    def perturb_point(self, Z, sampler, sigma: float = 0.05, h_min: float = 0.001, h_max: float = 0.02, redraw_h: bool = False):
+        """Z += N(0, sigma^2), h clipped (or redrawn uniformly): the evaluation point of SURVEY.md 8d, on the device."""
+        _lib.check(_lib.lib().qln_perturb_point(self._h, C.byref(sampler), self._check(Z, self.dims.z_total, "Z"), float(sigma),
+                                                float(h_min), float(h_max), int(redraw_h)))
+        return Z
+
+    def boundary_states(self):
+        """(x0, xf) as the handle holds them now, (B, 15) each."""
+        x0, xf = np.zeros((self.B, n)), np.zeros((self.B, n))
+        _lib.check(_lib.lib().qln_get_boundary_states(self._h, x0.ctypes.data, xf.ctypes.data))
+        return x0, xf
+
     def set_lqr_cost(self, Q, R, Qf, dt: float, per_problem: bool = False):
         """The notebook's objective (src/main.ipynb:158-161) built on the device from the handle's own k_trans /
         init_mode / xf; Q, Qf: 15 diagonal entries, R: 5."""

@@ -91,10 +91,10 @@ def make_batch(B: int, N: int = 40, k_trans=14, init_mode=1, *, seed: int = 0, r
         kt = np.full(B, k_trans, dtype=np.int32)
         im = np.full(B, init_mode, dtype=np.int32)
     x0 = np.tile(notebook_initial_state(model), (B, 1))
-    x0[:, 2] = np.deg2rad(rng.uniform(-40.0, -10.0, size=B))
-    x0[:, 6] = rng.uniform(0.1, 0.3, size=B)
-    x0[:, 8] = -np.sqrt(2 * 9.81 * rng.uniform(0.5, 2.5, size=B))
-    x0[:, 9] = rng.uniform(-np.pi / 2, 0.0, size=B)
+    x0[:, 2] = np.deg2rad(rng.uniform(*THETA0_DEG, size=B))
+    x0[:, 6] = rng.uniform(*Y2_0, size=B)
+    x0[:, 8] = -np.sqrt(2 * 9.81 * rng.uniform(*DROP_HEIGHT, size=B))
+    x0[:, 9] = rng.uniform(*OMEGA0, size=B)
     swap = im == 2                                              # mirror the feet for init_mode 2
     x0[swap, 3:5], x0[swap, 5:7] = x0[swap, 5:7].copy(), x0[swap, 3:5].copy()
     x0[swap, 10:12], x0[swap, 12:14] = x0[swap, 12:14].copy(), x0[swap, 10:12].copy()
@@ -114,6 +114,34 @@ def make_batch(B: int, N: int = 40, k_trans=14, init_mode=1, *, seed: int = 0, r
     else:
         Z[:, hcols] = np.clip(Z[:, hcols], 0.001, 0.02)
     return LandingBatch(model, N, kt, im, x0, xf, obj, Z)
+
+
+# ranges of the random drop states (the notebook's values are their centres)
+THETA0_DEG = (-40.0, -10.0)
+Y2_0 = (0.1, 0.3)
+DROP_HEIGHT = (0.5, 2.5)
+OMEGA0 = (-np.pi / 2, 0.0)
+
+
+def drop_state_sampler(seed: int, model: PlanarQuadruped | None = None, stream_offset: int = 0):
+    """The qln_drop_state_sampler that makes qln_sample_drop_states draw exactly what make_batch(seed=seed) draws on
+    the host for x0 (uniform k_trans / init_mode batches: the x0 draws are the first 4B of the stream; the ragged
+    workload consumes its k_trans / init_mode integers first, which have no closed-form position -- host only)."""
+    from . import _lib
+
+    model = model or PlanarQuadruped()
+    st = np.random.PCG64(seed).state["state"]
+    s = _lib.QlnDropStateSampler()
+    mask = (1 << 64) - 1
+    s.pcg_state[0], s.pcg_state[1] = st["state"] >> 64, st["state"] & mask
+    s.pcg_inc[0], s.pcg_inc[1] = st["inc"] >> 64, st["inc"] & mask
+    s.stream_offset = int(stream_offset)
+    for i, v in enumerate(notebook_initial_state(model)):
+        s.x0_template[i] = float(v)
+    for name, rng in (("theta_deg", THETA0_DEG), ("y2", Y2_0), ("drop_height", DROP_HEIGHT), ("omega", OMEGA0)):
+        getattr(s, name)[0], getattr(s, name)[1] = float(rng[0]), float(rng[1])
+    s.two_g = 2 * 9.81
+    return s
 
 
 def notebook_problem(N: int = 61, k_trans: int = 21, init_mode: int = 1, dt: float = 0.009,
