@@ -211,6 +211,18 @@ typedef struct qln_solve_options {
 #define QLN_SOLVE_INFO_STRIDE 16
 int qln_solve_default_options(qln_solve_options* opt);
 int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt /* NULL = defaults */, double* info);
+/* OPT-IN EXTENSION WITHOUT A REFERENCE ORACLE.  The leg-length ("kinematic") constraint group exists in the reference
+ * only as commented-out code (src/constraints.jl:115-138 values, :276-288 Jacobian, src/nlp.jl:60,70 index range and
+ * bounds): the reference never computes it, so nothing can be compared with it, and it is NOT part of c / vals above.
+ *   d[b][2k]   = |pb_k - p1_k|,  d[b][2k+1] = |pb_k - p2_k|      k = 0..N-1   (as the commented source defines them)
+ *   bounds     0 <= d <= l1 + l2 + lb/2                                        (qln_kinematic_bounds)
+ *   jac[b][2k+i][4] = d(row)/d(xb, yb, x_foot, y_foot) = (+e, -e) with e = (pb - p_foot)/|pb - p_foot|: the
+ *   mathematically correct Jacobian, in the columns 20k + {0, 1, 3, 4} (foot 1) / 20k + {0, 1, 5, 6} (foot 2) of Z --
+ *   the commented Jacobian indexes x[7:8] / x[9:10], which are not the feet, and is not reproduced.
+ * Checked against an independent numpy statement of the formula and its complex-step derivative only
+ * (tests/test_gpu_kinematic.py).  d: [B][2N] doubles, jac (may be NULL): [B][2N][4].  Device pointers, stream-ordered. */
+int qln_eval_kinematic_constraint(qln_handle* h, const double* Z, double* d, double* jac);
+int qln_kinematic_bounds(const qln_handle* h, double* lower, double* upper); /* the two scalars */
 /* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
  * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
  * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */

@@ -72,6 +72,7 @@ void cinds_of(int32_t N, int32_t kt, int32_t out[14]) {
 
 struct qln_handle {
     int device = 0;
+    qln_model model{};
     hipStream_t stream = nullptr;
     qln::BatchParams p{};
     qln_dims dims{};
@@ -200,6 +201,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     qln_handle* h = new (std::nothrow) qln_handle();
     if (!h) return fail(QLN_ERR_HIP, "qln_create: out of host memory");
     h->device = device;
+    h->model = d->model;
     h->k_trans.assign(d->k_trans, d->k_trans + d->B);
     h->init_mode.assign(d->init_mode, d->init_mode + d->B);
     h->c_off.resize(d->B);
@@ -537,6 +539,22 @@ int qln_jacobian_init_constants(qln_handle* h, double* vals) {
     if (int rc = check_vals(vals)) return rc;
     if (int rc = bind_device(h)) return rc;
     QLN_HIP(qln::launch_jacobian_constants(h->p, vals, h->stream));
+    return QLN_OK;
+}
+
+int qln_eval_kinematic_constraint(qln_handle* h, const double* Z, double* d, double* jac) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !d) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_kinematic_constraint: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_kinematic_rows(h->p, Z, d, jac, h->stream));
+    return QLN_OK;
+}
+
+int qln_kinematic_bounds(const qln_handle* h, double* lower, double* upper) {
+    if (int rc = check_handle(h)) return rc;
+    if (!lower || !upper) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_kinematic_bounds: null pointer");
+    *lower = 0.0;
+    *upper = h->model.l1 + h->model.l2 + h->model.lb / 2;  // src/nlp.jl:70 (commented out there)
     return QLN_OK;
 }
 

@@ -795,6 +795,30 @@ __global__ __launch_bounds__(256) void k_lqr_cost(BatchParams P, const double* _
     out[40] = a + bb;                                      // c = 0.5*xf'Q*xf + 0.5*uf'R*uf
 }
 
+// Opt-in extension, NOT on the reference's path: the leg-length ("kinematic") rows the reference carries only as
+// commented-out code (src/constraints.jl:115-138: d[2k-1] = norm(pb - p1), d[2k] = norm(pb - p2); bounds
+// 0 <= d <= l1 + l2 + lb/2, src/nlp.jl:60,70).  Values as that source defines them; the Jacobian is the mathematically
+// correct one, d/d(pb) = (pb - p_i)/|pb - p_i| and d/d(p_i) = -(pb - p_i)/|pb - p_i| in the slots of pb, p1, p2 (the
+// commented Jacobian, :276-288, reads x[7:8] / x[9:10] -- y2, vbx / vby, omega -- which are not the feet).
+// One thread per (problem, knot): 6 doubles in, 2 + 8 out.
+__global__ __launch_bounds__(256) void k_kinematic_rows(BatchParams P, const double* __restrict__ Z, double* __restrict__ D,
+                                                       double* __restrict__ JV) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)P.B * P.N) return;
+    const int b = (int)(t / P.N), k = (int)(t - (int64_t)b * P.N);
+    const double* x = Z + (int64_t)b * P.z_stride + 20 * k;
+    const double xb = x[0], yb = x[1];
+    const double d1x = xb - x[3], d1y = yb - x[4], d2x = xb - x[5], d2y = yb - x[6];
+    const double n1 = sqrt(d1x * d1x + d1y * d1y), n2 = sqrt(d2x * d2x + d2y * d2y);
+    D[2 * t] = n1;
+    D[2 * t + 1] = n2;
+    if (JV) {
+        double* j = JV + 8 * t;
+        j[0] = d1x / n1, j[1] = d1y / n1, j[2] = -d1x / n1, j[3] = -d1y / n1;
+        j[4] = d2x / n2, j[5] = d2y / n2, j[6] = -d2x / n2, j[7] = -d2y / n2;
+    }
+}
+
 template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
@@ -897,6 +921,12 @@ hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, dou
         if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
         else hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_kinematic_rows(const BatchParams& p, const double* Z, double* d, double* jac_vals, hipStream_t stream) {
+    const int64_t n = (int64_t)p.B * p.N;
+    hipLaunchKernelGGL(k_kinematic_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, Z, d, jac_vals);
     return hipGetLastError();
 }
 

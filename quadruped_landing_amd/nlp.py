@@ -445,6 +445,19 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_solve(self._h, Z.data_ptr(), C.byref(opt), info.data_ptr()))
         return Z, info.view(self.B, _lib.SOLVE_INFO_STRIDE)
 
+    def kinematic_constraint(self, Z, with_jacobian: bool = True):
+        """OPT-IN, nothing in the reference to compare with: the leg-length rows the reference has only as commented-out code
+        (src/constraints.jl:115-138).  Returns (d (B, 2N), jac (B, 2N, 4) or None, (lower, upper))."""
+        t = _torch()
+        self._check(Z, self.dims.z_total, "Z")
+        d = t.empty(self.B * 2 * self.N, dtype=t.float64, device=self._dev())
+        jac = t.empty(self.B * 8 * self.N, dtype=t.float64, device=self._dev()) if with_jacobian else None
+        _lib.check(_lib.lib().qln_eval_kinematic_constraint(self._h, Z.data_ptr(), d.data_ptr(),
+                                                            jac.data_ptr() if jac is not None else None))
+        lo, up = C.c_double(), C.c_double()
+        _lib.check(_lib.lib().qln_kinematic_bounds(self._h, C.byref(lo), C.byref(up)))
+        return d.view(self.B, 2 * self.N), (jac.view(self.B, 2 * self.N, 4) if jac is not None else None), (lo.value, up.value)
+
     def constraint_violation(self, c, out=None):
         """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
         out = self.new_f() if out is None else out
