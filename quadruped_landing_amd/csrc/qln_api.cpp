@@ -907,11 +907,11 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
     prop.location.id = h->device;
     size_t gran = 0;
     QLN_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    // Physical chunks of 256 MiB.  Larger ones buy nothing (launch times are the same from 2 MiB to 1 GiB,
-    // profiles/r01_vmm_placement.txt) and chunks of 2 GiB and more are not usable on ROCm 7.2: a range built as
-    // hipMemAddressReserve(8 GiB) + 4 x {hipMemCreate(2 GiB), hipMemMap} + hipMemSetAccess(whole range) raised a GPU
-    // memory access fault under the first kernel that wrote it (bench/vmm_placement.cpp, round 1), with every call
-    // returning hipSuccess -- the same program is clean with chunks of 1 GiB and less.
+    // Physical chunks of 256 MiB: launch times are the same from 2 MiB to 1 GiB (profiles/r01_vmm_placement.txt), and a
+    // finer chunk makes the window scan finer.  (Round 1 recorded "chunks of 2 GiB and more raise a GPU memory access
+    // fault": that program had unmapped, freed and re-reserved the same range a dozen times before it got to that size,
+    // i.e. it ran into the address-reuse defect described at kReturnVirtualRange.  On a fresh range 2-GiB chunks are
+    // fine: bench/vmm_big_chunk.cpp, profiles/r02_vmm_big_chunk.txt.)
     const size_t chunk = round_up((int64_t)256 << 20, (int64_t)gran);
     const size_t bytes = (size_t)h->dims.j_total * 8;
     const size_t need = (bytes + chunk - 1) / chunk;                     // chunks under vals
