@@ -23,6 +23,7 @@
 // (src/planar_quadruped.jl:225-248) up to rounding.
 #include "qln_kernel_common.h"
 
+#include <algorithm>
 #include <type_traits>
 
 #ifdef QLN_TUNING
@@ -633,16 +634,60 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
     if (lane == 0) F[b] = J;
 }
 
+// The same for the common case of ONE cost table shared by the whole batch (cost_batch == 1) and N <= 64: persistent
+// workgroups of four waves stage the 41 N doubles of the table in LDS once and then walk the batch, one problem per wave
+// at a time -- lane = knot reads its record from LDS (stride 41 doubles: odd, no bank conflicts) instead of issuing 41
+// scattered 8-byte requests per lane to the texture path, which is what bounds k_objective on this workload -- and the next
+// problem's slice of Z is in flight while the current one is summed.
+__global__ __launch_bounds__(4 * kWave) void k_objective_shared(BatchParams P, const double* __restrict__ Z,
+                                                                double* __restrict__ F) {
+    extern __shared__ double s_dyn[];
+    const int N = P.N;
+    const int n_nlp = 20 * N - 5;
+    double* s_cost = s_dyn;                                   // [N][41]
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int per_wave = 20 * N + kWave;
+    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * per_wave;  // [20 N]
+    double* s_term = s_z + 20 * N;                               // [64]
+    for (int i = threadIdx.x; i < 41 * N; i += blockDim.x) s_cost[i] = P.cost[i];
+    __syncthreads();
+    constexpr int kIters = 20;
+    const int stride = gridDim.x * 4;
+    int b = blockIdx.x * 4 + wave;
+    double zr[kIters];
+    if (b < P.B) {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)b * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+    }
+    for (; b < P.B; b += stride) {
+        wave_lds_sync();  // the previous problem's readers are done
+#pragma unroll
+        for (int it = 0; it < kIters; ++it)
+            if (it * kWave + lane < 20 * N) s_z[it * kWave + lane] = zr[it];
+        wave_lds_sync();
+        const int bn = b + stride;  // the next problem's slice, in flight during this one's sums
+        if (bn < P.B) {
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)bn * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+        }
+        const int kl = min(lane, N - 1);
+        const double term = objective_term(s_z + 20 * kl, s_cost + 41 * kl, kl < N - 1);
+        const double J = add_terms_in_order(0.0, (lane < N) ? term : 0.0, s_term, lane);
+        if (lane == 0) F[b] = J;
+    }
+}
+
 // Objective gradient (src/costs.jl:23-34; no d(h*l)/dh term -- quirk Q2).  Flat over the entries of the whole batch
 // (a problem's 20N-5 entries do not fill whole workgroups): 1024 consecutive entries per workgroup, four per thread,
 // loads issued before the first store.
+constexpr int kGradU = 4;  // entries per thread (8, and non-temporal stores, measured: no gain)
 __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const double* __restrict__ Z,
                                                            double* __restrict__ G, int64_t total, int ntiles) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
     const int tile = xcd_contiguous_index(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
-    constexpr int kU = 4;
+    constexpr int kU = kGradU;
     double z[kU], D[kU], d[kU], h[kU];
     int64_t at[kU];
     bool stage[kU];
@@ -936,6 +981,16 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 }
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
+    if (p.cost_batch == 1 && p.N <= kWave && p.B >= 4096) {
+        // one shared cost table: persistent four-wave workgroups with the table in LDS (three per CU at N = 40)
+        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + 4 * (20 * p.N + kWave)) * sizeof(double);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+        const int grid = std::min(256 * per_cu, (p.B + 3) / 4);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_shared), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_objective_shared, dim3(grid), dim3(4 * kWave), lds, stream, p, Z, f);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
     return hipGetLastError();
 }
@@ -961,7 +1016,7 @@ hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t str
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
     const int64_t total = (int64_t)p.B * (20 * p.N - 5);
-    const int ntiles = (int)((total + 1023) / 1024);
+    const int ntiles = (int)((total + kGradU * 256 - 1) / (kGradU * 256));
     hipLaunchKernelGGL(k_objective_gradient, dim3(xcd_grid(ntiles)), dim3(256), 0, stream, p, Z, grad, total, ntiles);
     return hipGetLastError();
 }
