@@ -194,16 +194,17 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
  * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~140).  Stream-ordered. */
 typedef struct qln_solve_options {
-    int32_t max_outer;        /* multiplier updates                                   default 30   */
-    int32_t max_inner;        /* iLQR iterations per multiplier update                default 60   */
+    int32_t max_outer;        /* multiplier updates                                   default 80   */
+    int32_t max_inner;        /* iLQR iterations per multiplier update (inexact inner solves pay)   default 8 */
     double tol_violation;     /* stop when the violation is <= this                   default 1e-6 (solve()'s c_tol) */
     double inner_tol;         /* inner loop ends when the cost decrease is below inner_tol (1 + |J|)   default 1e-7 */
-    double rho0, rho_factor, rho_max;  /* penalty schedule                            default 1, 10, 1e8 */
+    double rho0, rho_factor, rho_max;  /* penalty schedule                            default 10, 5, 1e8 */
     double h_min, h_max;      /* bounds on the step length (src/moi.jl:58-61)         default 0.001, 0.02 */
     double theta_min, theta_max;       /* bounds on the body angle (src/moi.jl:54-56) default -pi/2, pi/2 */
     int32_t q6_bounds;        /* the lower bounds of quirk Q6 (yb_{k+1}, x1_{k+1} >= 0, src/moi.jl:64-65)  default 1 */
     int32_t exact_h_gradient; /* 0: objective gradient as the reference's grad_f!, which has no d(h l)/dh (quirk Q2) --
-                                 the stage weights h_k are frozen within an iteration; 1: the exact gradient  default 0 */
+                                 the stage weights h_k are frozen within an iteration; 1: the exact gradient (couples the
+                                 step lengths to the cost: use tighter inner solves, max_inner ~30)             default 0 */
     double h_prox;            /* proximal weight on the step lengths in the Newton system (it vanishes at a fixed point):
                                  with the reference's gradient the objective does not see h, the h_k are fixed by the
                                  constraints alone and wander along flat directions without it          default 1e4 */
