@@ -212,6 +212,9 @@ typedef struct qln_solve_options {
 #define QLN_SOLVE_INFO_STRIDE 16
 int qln_solve_default_options(qln_solve_options* opt);
 int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt /* NULL = defaults */, double* info);
+/* the same with HOST pointers (MOI-mode style: Z copied in, solved on the GPU, copied back; synchronous) -- what the
+ * Julia veneer calls in place of `solve(Z0, nlp)`.  info (host, may be NULL): [B][QLN_SOLVE_INFO_STRIDE]. */
+int qln_solve_host(qln_handle* h, double* Z, const qln_solve_options* opt, double* info);
 /* OPT-IN EXTENSION WITHOUT A REFERENCE ORACLE.  The leg-length ("kinematic") constraint group exists in the reference
  * only as commented-out code (src/constraints.jl:115-138 values, :276-288 Jacobian, src/nlp.jl:60,70 index range and
  * bounds): the reference never computes it, so nothing can be compared with it, and it is NOT part of c / vals above.

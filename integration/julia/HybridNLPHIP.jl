@@ -85,3 +85,28 @@ function MOI.jacobian_structure(nlp::HybridNLPHIP)                      # src/mo
     qln_check(ccall((:qln_jacobian_structure, LIBQLN), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}), nlp.handle, 0, rows, cols))
     return [(Int(r) + 1, Int(c) + 1) for (r, c) in zip(rows, cols)]     # the ABI is 0-based
 end
+
+# ---- beyond the evaluator: the same NLP solved on the GPU in place of `solve(Z0, nlp)` (src/moi.jl:46-103) -------------
+# qln_solve_host: augmented-Lagrangian iLQR, one wavefront per problem (DESIGN.md 4.6); objective, constraint bounds and the
+# variable bounds of solve() (quirk Q6 included) are the reference's.  Field order = include/qln_evaluator.h.
+struct QlnSolveOptions
+    max_outer::Int32; max_inner::Int32
+    tol_violation::Cdouble; inner_tol::Cdouble
+    rho0::Cdouble; rho_factor::Cdouble; rho_max::Cdouble
+    h_min::Cdouble; h_max::Cdouble; theta_min::Cdouble; theta_max::Cdouble
+    q6_bounds::Int32; exact_h_gradient::Int32
+    h_prox::Cdouble
+end
+
+function solve_hip(x0, prob::HybridNLPHIP; c_tol=1.0e-6)
+    opt = Ref{QlnSolveOptions}()
+    qln_check(ccall((:qln_solve_default_options, LIBQLN), Cint, (Ref{QlnSolveOptions},), opt))
+    o = opt[]
+    opt[] = QlnSolveOptions(o.max_outer, o.max_inner, c_tol, o.inner_tol, o.rho0, o.rho_factor, o.rho_max, o.h_min, o.h_max,
+                            o.theta_min, o.theta_max, o.q6_bounds, o.exact_h_gradient, o.h_prox)
+    Z = collect(Float64, x0)             # in: initial guess (its controls are used); out: the solution
+    info = zeros(16)                     # {outer, iLQR iterations, f, violation, rho, status, ...}
+    qln_check(ccall((:qln_solve_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{QlnSolveOptions}, Ptr{Cdouble}),
+                    prob.handle, Z, opt, info))
+    return Z, info
+end

@@ -138,6 +138,7 @@ SIGNATURES = {
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
     "qln_solve_default_options": (C.c_int, [C.POINTER(QlnSolveOptions)]),
     "qln_solve": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
+    "qln_solve_host": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
     "qln_sample_drop_states": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler)]),
     "qln_perturb_point": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler), _dp, C.c_double, C.c_double, C.c_double, C.c_int]),

@@ -712,6 +712,26 @@ int qln_get_boundary_states(qln_handle* h, double* x0, double* xf) {
     return QLN_OK;
 }
 
+int qln_solve_host(qln_handle* h, double* Z, const qln_solve_options* opt, double* info) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_solve_host: null Z");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ensure(&h->s_Z, h->dims.z_total)) return rc;
+    double* d_info = nullptr;
+    const size_t ninfo = (size_t)h->dims.B * QLN_SOLVE_INFO_STRIDE;
+    if (info) QLN_HIP(hipMalloc(reinterpret_cast<void**>(&d_info), ninfo * sizeof(double)));
+    int rc = QLN_OK;
+    hipError_t e = hipMemcpyAsync(h->s_Z, Z, h->dims.z_total * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) rc = qln_solve(h, h->s_Z, opt, d_info);
+    if (e == hipSuccess && rc == QLN_OK) e = hipMemcpyAsync(Z, h->s_Z, h->dims.z_total * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && rc == QLN_OK && info) e = hipMemcpyAsync(info, d_info, ninfo * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && rc == QLN_OK) e = hipStreamSynchronize(h->stream);
+    if (d_info) (void)hipFree(d_info);
+    if (rc != QLN_OK) return rc;
+    if (e != hipSuccess) return fail(QLN_ERR_HIP, std::string("qln_solve_host: ") + hipGetErrorString(e));
+    return QLN_OK;
+}
+
 int qln_initial_guess(qln_handle* h, double* Z) {
     if (int rc = check_handle(h)) return rc;
     if (!Z) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_initial_guess: null Z");

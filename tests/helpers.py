@@ -47,9 +47,10 @@ def build_c_host(out_dir):
     return exe
 
 
-def write_problem_file(path, nb, Z):
+def write_problem_file(path, nb, Z, Z0=None):
     m = nb.model
     with open(path, "w") as fh:
         fh.write(f"{nb.N} {int(nb.k_trans[0])} {int(nb.init_mode[0])}\n")
-        for arr in ([m.g, m.mb, m.mf, m.lb, m.l1, m.l2], nb.x0[0], nb.xf[0], np.asarray(nb.obj).reshape(-1), Z):
+        for arr in ([m.g, m.mb, m.mf, m.lb, m.l1, m.l2], nb.x0[0], nb.xf[0], np.asarray(nb.obj).reshape(-1), Z) + (
+                (Z0,) if Z0 is not None else ()):
             fh.write(" ".join(repr(float(x)) for x in np.asarray(arr).reshape(-1)) + "\n")

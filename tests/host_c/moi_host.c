@@ -9,6 +9,8 @@
  *   eval_constraint_jacobian, dense   qln_eval_constraint_jacobian_dense_host(0, x, vec[m_nlp*n_nlp])  (:15-24)
  *   eval_constraint_jacobian, sparse  qln_eval_constraint_jacobian_host(x, vec[nnz])
  *   jacobian_structure                qln_jacobian_structure(0, rows, cols)                     (src/moi.jl:31-33)
+ *   solve(Z0, nlp)   qln_solve_host(Z0) -- the GPU solve of the same NLP in place of Ipopt (src/moi.jl:46-103), if the
+ *                    problem file carries a second vector z0[n_nlp]; judged by qln_eval_constraint_host on the result
  *   finalizer        qln_destroy
  *
  * Buffers are caller-malloc'd with exactly the sizes Ipopt hands the callbacks (m_nlp, n_nlp, m_nlp*n_nlp, nnz): the
@@ -72,6 +74,13 @@ int main(int argc, char** argv) {
     const int n_nlp = 20 * N - 5;
     double* x = guarded((size_t)n_nlp, 0.0);
     read_doubles(fp, x, (size_t)n_nlp);
+    double* z0 = guarded((size_t)n_nlp, 0.0);
+    int have_z0 = 1;
+    for (int i = 0; i < n_nlp; ++i)
+        if (fscanf(fp, "%lf", &z0[i]) != 1) {
+            have_z0 = 0;
+            break;
+        }
     fclose(fp);
 
     /* HybridNLPHIP(model, obj, init_mode, k_trans, N, x0, xf): B = 1, defaults for stride / alignment */
@@ -136,7 +145,19 @@ int main(int argc, char** argv) {
     }
     printf("sparse_in_range=%ld\nsparse_equals_dense=%ld\n", in_range, agree);
 
-    const int ok = guards_intact(x, (size_t)n_nlp) && guards_intact(lb, (size_t)m_nlp) && guards_intact(ub, (size_t)m_nlp) &&
+    if (have_z0) {
+        /* solve(Z0, nlp) on the GPU, then the evaluator's verdict on what came back */
+        double sinfo[QLN_SOLVE_INFO_STRIDE];
+        QK(qln_solve_host(h, z0, NULL, sinfo));
+        double fs = 0.0;
+        QK(qln_eval_objective_host(h, z0, &fs));
+        QK(qln_eval_constraint_host(h, z0, g));
+        double sv = 0.0;
+        for (int i = 0; i < n_eq; ++i) sv = fmax(sv, fabs(g[i]));
+        for (int i = n_eq; i < m_nlp; ++i) sv = fmax(sv, fmax(-g[i], 0.0));
+        printf("solve_status=%d\nsolve_iterations=%d\nsolve_f=%.17g\nsolve_violation=%.17g\n", (int)sinfo[5], (int)sinfo[1], fs, sv);
+    }
+    const int ok = guards_intact(z0, (size_t)n_nlp) && guards_intact(x, (size_t)n_nlp) && guards_intact(lb, (size_t)m_nlp) && guards_intact(ub, (size_t)m_nlp) &&
                    guards_intact(grad, (size_t)n_nlp) && guards_intact(g, (size_t)m_nlp) && guards_intact(jac, nd) &&
                    guards_intact(vals, (size_t)nnz);
     printf("guards_intact=%d\n", ok);

@@ -211,7 +211,7 @@ def test_c_host_makes_the_julia_bindings_call_sequence(tmp_path, golden_dir):
     nb = PG.notebook_problem()
     Z = np.loadtxt(os.path.join(golden_dir, "data_6.csv"))
     pf = tmp_path / "problem.txt"
-    write_problem_file(pf, nb, Z)
+    write_problem_file(pf, nb, Z, Z0=nb.Z[0])
     out = subprocess.run([str(exe), str(pf)], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0
@@ -227,3 +227,6 @@ def test_c_host_makes_the_julia_bindings_call_sequence(tmp_path, golden_dir):
     assert int(kv["dense_write_set"]) == write_set == 32161
     assert int(kv["nnz"]) == int(kv["sparse_in_range"]) == int(kv["sparse_equals_dense"])
     assert int(kv["nnz"]) == write_set - 210 * (N - 1)  # the COO list leaves out the off-diagonal zeros of the -I blocks
+    # ... and solve(Z0, nlp) itself from the C host: the GPU solve reaches the feasibility of the reference's Ipopt run
+    assert kv["solve_status"] == "0" and float(kv["solve_violation"]) <= 1.4928675395736724e-06
+    assert 90.0 <= float(kv["solve_f"]) <= 125.0
