@@ -455,25 +455,34 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 }
                 wave_lds_sync();
             }
+            // A and B hold zeros wherever the union pattern has no entry: written once, the per-knot scatter below touches
+            // exactly the pattern's 85 positions.  What a knot needs from global memory -- its step-block entries and its
+            // cost record -- is requested one knot ahead, so that the L2 round trip is off the sweep's dependency chain.
+            for (int e = lane; e < 300; e += kWave) L.A[e] = 0.0;
+            double pf_e0, pf_e1, pf_D, pf_d;
+            auto prefetch = [=](int k, double& e0, double& e1, double& cD, double& cd) {
+                const double* e = ent + (int64_t)k * kEnt;
+                e0 = e[lane];
+                e1 = e[min(lane + 64, kStepUnion - 1)];
+                const double* rec = costg + 41 * k;
+                cD = rec[min(lane, 19)];
+                cd = rec[20 + min(lane, 19)];
+            };
+            prefetch(N - 2, pf_e0, pf_e1, pf_D, pf_d);
             for (int k = N - 2; k >= 0 && pd_ok; --k) {
                 const double* kn = L.kn + kKn * k;
-                const double* rec = costg + 41 * k;
                 const double w = kn[KN_W];
-                // A (15x15), B (15x5) from the scratch entries
-                for (int e = lane; e < 300; e += kWave) L.A[e] = 0.0;  // A and B
-                wave_lds_sync();
-                {
-                    const double* e = ent + (int64_t)k * kEnt;
-                    const double v0 = e[lane], v1 = e[min(lane + 64, kStepUnion - 1)];
-                    L.A[L.map[lane]] = v0;
-                    if (lane + 64 < kStepUnion) L.A[L.map[lane + 64]] = v1;
-                }
+                const double v0 = pf_e0, v1 = pf_e1, recD = pf_D, recd = pf_d;
+                if (k > 0) prefetch(k - 1, pf_e0, pf_e1, pf_D, pf_d);
+                // A (15x15), B (15x5) from the entries
+                L.A[L.map[lane]] = v0;
+                if (lane + 64 < kStepUnion) L.A[L.map[lane + 64]] = v1;
                 // stage gradient (20) and the Gauss-Newton Hessian: diagonal + the (yb, theta) and (F1y, F2y) couplings
                 if (lane < 20) {
                     const int i = lane;
                     const double zi = (i < 15) ? L.X[15 * k + i] : L.U[5 * k + (i - 15)];
-                    double gi = w * (rec[i] * zi + rec[20 + i]);
-                    double hi = w * rec[i];
+                    double gi = w * (recD * zi + recd);
+                    double hi = w * recD;
                     if (k >= 1) {
                         if (i == 1) {
                             gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
@@ -663,21 +672,20 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         L.K[15 * i + lane] = kc[i];
                         Kg[(int64_t)kKg * k + 16 * i + lane] = kc[i];
                     }
+                    // M = Quu K + Qux, column `lane`, by the lane that holds that column of K (-> S, reused)
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        double acc = L.Qux[15 * r + lane];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) acc = fma(q[r][i], kc[i], acc);
+                        L.S[15 * r + lane] = acc;
+                    }
                 }
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) L.D[5 * k + i] = dff[i];
                 }
-                wave_lds_sync();
-                // M = Quu K + Qux (5x15) -> S (reused); m5 = Quu d + Qu
-                for (int e = lane; e < 75; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;
-                    double acc = L.Qux[e];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = fma(L.Quu[5 * r + i], L.K[15 * i + c], acc);  // (q[r][i] with a per-lane r would push q into scratch memory)
-                    L.S[e] = acc;
-                }
-                double m5[5];
+                double m5[5];  // Quu d + Qu
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     double acc = L.Qu[i];
@@ -686,16 +694,20 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     m5[i] = acc;
                 }
                 wave_lds_sync();
-                // P <- Qxx + K'M + Qux'K (-> T, then symmetrised into P);  pv <- Qx + K'm5 + Qux'd
+                // P <- sym(Qxx + K'M + Qux'K), written straight into P (nothing of this phase reads P): entry (r, c) is
+                // the mean of the expression and of its transpose, formed by the same lane;  pv <- Qx + K'm5 + Qux'd
                 for (int e = lane; e < 225; e += kWave) {
                     const int r = e / 15, c = e - 15 * r;
-                    double acc = L.Qxx[e];
+                    double acc = L.Qxx[e], act = L.Qxx[15 * c + r];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        acc = fma(L.K[15 * i + r], L.S[15 * i + c], acc);
-                        acc = fma(L.Qux[15 * i + r], L.K[15 * i + c], acc);
+                        const double kr = L.K[15 * i + r], kcn = L.K[15 * i + c];
+                        acc = fma(kr, L.S[15 * i + c], acc);
+                        acc = fma(L.Qux[15 * i + r], kcn, acc);
+                        act = fma(kcn, L.S[15 * i + r], act);
+                        act = fma(L.Qux[15 * i + c], kr, act);
                     }
-                    L.T[e] = acc;
+                    L.P[e] = 0.5 * (acc + act);
                 }
                 if (lane < 15) {
                     double acc = L.Qx[lane];
@@ -705,11 +717,6 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         acc = fma(L.Qux[15 * i + lane], dff[i], acc);
                     }
                     L.pv[lane] = acc;
-                }
-                wave_lds_sync();
-                for (int e = lane; e < 225; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;
-                    L.P[e] = 0.5 * (L.T[e] + L.T[15 * c + r]);
                 }
                 wave_lds_sync();
             }

@@ -104,3 +104,30 @@ def test_solve_is_deterministic_and_independent_of_batch_position():
     torch.cuda.synchronize()
     assert torch.equal(Z.view(9, -1)[4], Z1.view(1, -1)[0])
     assert torch.equal(info[4][:10], info1[0][:10])  # (entries 10-14 are phase timers)
+
+
+def test_long_horizon_with_per_problem_transition_knots():
+    """N = 80 (more knots than lanes: the per-knot phases loop over two chunks) and a different transition knot per
+    problem: every one solved, judged by the evaluator."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG, quadratic_cost as QC
+    from quadruped_landing_amd.ref_traj import reference_trajectory
+
+    B, N = 96, 80
+    base = PG.make_batch(B, N, 20, 1, seed=13, noise=0.0, build_obj=False)
+    kt = np.random.default_rng(5).integers(10, 41, size=B).astype(np.int32)
+    nlp = HybridNLP(base.model, None, 1, kt, N, base.x0, base.xf)
+    nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=True)  # Xref/Uref depend on k_trans
+    Z, info = nlp.solve(nlp.initial_guess())
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    print(f"N=80, k_trans in [10, 40]: status counts {np.bincount(inf[:, 5].astype(int), minlength=3)}, iLQR iterations median "
+          f"{np.median(inf[:, 1]):.0f} max {inf[:, 1].max():.0f}, violation max {viol.max():.2e}")
+    assert (inf[:, 5] == 0).mean() >= 0.98
+    ok = inf[:, 5] == 0
+    assert viol[ok].max() <= 1e-6 * 1.0001 and bviol[ok].max() <= 1e-6
+    for b in np.nonzero(ok)[0][:8]:  # dynamics / contact rows of a rolled-out trajectory are exactly zero
+        ci = nlp.cinds(int(b))
+        seg = nlp.split_c(c, int(b))
+        assert np.all(seg[ci[2][0] - 1 : ci[4][1]] == 0.0)
