@@ -1,4 +1,4 @@
-"""The JSON line bench.py prints (the committed line of the round's final run, profiles/r01_bench.json) carries every
+"""The JSON line bench.py prints (the committed line of the round's final run, profiles/r02_bench.json) carries every
 field of the driver's contract, and its numbers are consistent with each other and with SURVEY.md 8d's byte counts."""
 import json
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields_and_consistent_numbers():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -39,3 +39,30 @@ def test_committed_bench_line_has_the_contract_fields_and_consistent_numbers():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     # north star: >= 1e7 knot-evals/s at >= 40 % of the HBM roofline
     assert d["value"] >= 1e7 and r["frac"] >= 0.40
+    # the measured traffic is quoted for the build it was taken on, and says where it comes from
+    assert "traffic_source" in r and "rocprofv3" in r["traffic_source"]
+    # the caller side on BASELINE.json configs[1]: every problem solved, judged by the evaluator
+    sv = d["other"]["solve_config2_B1024_N40"]
+    assert sv["problems"] == 1024 and sv["solved_to_1e-6"] == 1024 and sv["violation_max"] <= 1e-6 * 1.0001
+    assert sv["solved_problems_per_s"] > 1e3
+
+
+def test_kernel_build_id_is_stable_and_traffic_lookup_refuses_other_builds(tmp_path, monkeypatch):
+    """bench.measured_traffic quotes profiles/traffic.json only for the kernel build it was measured on."""
+    import json as J
+
+    bid = bench.kernel_build_id()
+    assert len(bid) == 16 and bid == bench.kernel_build_id()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "quadruped_landing_amd" / "csrc")
+    for f in ("qln_kernels.hip", "qln_kernel_common.h", "qln_device.h"):
+        (tmp_path / "quadruped_landing_amd" / "csrc" / f).write_text("x" + f)
+    here = bench.kernel_build_id()
+    J.dump({"config3": {"hbm_bytes_per_launch": 7.0e9, "build_id": here, "profile": "p"},
+            "config4": {"hbm_bytes_per_launch": 1.4e10, "build_id": "somethingelse"}}, open(tmp_path / "profiles" / "traffic.json", "w"))
+    assert bench.measured_traffic("config3")[0] == 7.0e9
+    t, why = bench.measured_traffic("config4")
+    assert t is None and "not quoted" in why
+    t, why = bench.measured_traffic("config2")
+    assert t is None and "no PMC profile" in why
