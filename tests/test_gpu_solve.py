@@ -131,3 +131,51 @@ def test_long_horizon_with_per_problem_transition_knots():
         ci = nlp.cinds(int(b))
         seg = nlp.split_c(c, int(b))
         assert np.all(seg[ci[2][0] - 1 : ci[4][1]] == 0.0)
+
+
+def test_solve_rejects_what_it_cannot_do():
+    """Error behaviour of the boundary: no cost table, bad options, a horizon that does not fit a CU's LDS."""
+    from quadruped_landing_amd import HybridNLP, _lib, problem_gen as PG
+
+    b = PG.make_batch(2, 12, 5, 1, seed=1, build_obj=False)
+    nlp = HybridNLP(b.model, None, b.init_mode, b.k_trans, b.N, b.x0, b.xf)
+    Z = nlp.upload_Z(b.Z)
+    with pytest.raises(_lib.QlnError) as e:
+        nlp.solve(Z)
+    assert e.value.code == _lib.QLN_ERR_INVALID_ARGUMENT and "cost" in str(e.value)
+    nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009)
+    for bad in (dict(max_inner=0), dict(tol_violation=0.0), dict(rho_factor=1.0), dict(h_min=0.0), dict(h_max=0.0005), dict(h_prox=-1.0)):
+        with pytest.raises(_lib.QlnError) as e:
+            nlp.solve(Z, **bad)
+        assert e.value.code == _lib.QLN_ERR_INVALID_ARGUMENT, bad
+    with pytest.raises(TypeError):
+        nlp.solve(Z, no_such_option=1)
+    big = PG.make_batch(1, 500, 50, 1, seed=1)  # 47 N + 1.4k doubles of LDS: N <= ~400 fits the 160 KB of a CU
+    nb = HybridNLP(big.model, big.obj, big.init_mode, big.k_trans, big.N, big.x0, big.xf)
+    with pytest.raises(_lib.QlnError) as e:
+        nb.solve(nb.upload_Z(big.Z))
+    assert e.value.code == _lib.QLN_ERR_UNSUPPORTED
+
+
+def test_transition_knot_extremes():
+    """k_trans at the ends of its range (the jump at the first / last dynamics knot): the solver terminates with a finite
+    trajectory whose roll-out rows are exact, and solves the ones that are feasible landings."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    N = 30
+    base = PG.make_batch(8, N, 10, 1, seed=2, noise=0.0, build_obj=False)
+    kt = np.array([2, 3, 4, N - 2, N - 1, N, 10, 15], dtype=np.int32)
+    nlp = HybridNLP(base.model, None, 1, kt, N, base.x0, base.xf)
+    nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=True)
+    Z, info = nlp.solve(nlp.initial_guess())
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    print("k_trans", kt.tolist(), "status", inf[:, 5].astype(int).tolist(), "violation", [f"{v:.1e}" for v in viol])
+    assert np.all(np.isfinite(Zh)) and np.all(np.isfinite(f))
+    for b in range(8):
+        ci = nlp.cinds(b)
+        seg = nlp.split_c(c, b)
+        assert np.all(seg[: 15] == 0.0) and np.all(seg[ci[2][0] - 1 : ci[4][1]] == 0.0), b  # init, dynamics, contact rows
+    assert (inf[:, 5] == 0).sum() >= 6

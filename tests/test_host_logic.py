@@ -135,3 +135,47 @@ def test_bench_strict_nnz_counts_match_oracle_structure():
     vals = prob.jac_c_coo(Z)
     dyn_nnz = int(np.count_nonzero(vals[: 300 * (N - 1)]))
     assert int(bench.strict_bytes(N, kt)) == 8 * (20 * N - 5) + 8 * prob.m_nlp + 8 * (dyn_nnz + N)
+
+
+def test_ipopt_initial_point_pushes_exactly_the_bounded_variables_inside():
+    """nlp.ipopt_initial_point (the point of Ipopt's iteration 0, KA6): variables without bounds are untouched, bounded
+    ones end strictly inside their relaxed bounds, a point already far inside is untouched, and the push distances are
+    Ipopt's (bound_push relative to max(1, |bound|), capped by bound_frac of the range when both bounds exist)."""
+    import numpy as np
+    from quadruped_landing_amd import nlp as NL
+
+    N = 9
+    xl, xu = NL.variable_bounds(N)
+    Z = np.zeros(NL.num_primals(N))
+    Z[19::20] = 0.001            # time steps on their lower bound
+    Z[2::20] = 2.0               # theta beyond its upper bound pi/2
+    Zp = NL.ipopt_initial_point(Z, xl, xu)
+    free = ~np.isfinite(xl) & ~np.isfinite(xu)
+    assert np.array_equal(Zp[free], Z[free])
+    both = np.isfinite(xl) & np.isfinite(xu)
+    assert np.all(Zp[both] > xl[both] - 1e-8) and np.all(Zp[both] < xu[both] + 1e-8)
+    h = Zp[19::20]
+    assert np.allclose(h, 0.001 - 1e-8 + 0.01 * (0.019 + 2e-8), rtol=0, atol=1e-15)   # bound_frac of the (relaxed) range
+    th = Zp[2::20]
+    up = np.pi / 2 + 1e-8 * (np.pi / 2)   # relaxed by bound_relax_factor * max(1, |bound|)
+    assert np.allclose(th, up - 0.01 * up, rtol=0, atol=1e-15)  # bound_push * |bound| = 0.0157 < bound_frac * range
+    lower_only = np.isfinite(xl) & ~np.isfinite(xu)
+    assert np.allclose(Zp[lower_only], -1e-8 + 0.01, rtol=0, atol=1e-15)   # yb_{k+1}, x1_{k+1} >= 0 (quirk Q6), pushed to 0.01
+    inside = Z.copy()
+    inside[19::20] = 0.01
+    inside[2::20] = 0.3
+    inside[lower_only] = 0.5
+    assert np.array_equal(NL.ipopt_initial_point(inside, xl, xu), inside)
+
+
+def test_drop_state_sampler_carries_numpys_pcg64_state():
+    import numpy as np
+    from quadruped_landing_amd import problem_gen as PG
+
+    s = PG.drop_state_sampler(7, stream_offset=12)
+    st = np.random.PCG64(7).state["state"]
+    assert (int(s.pcg_state[0]) << 64) | int(s.pcg_state[1]) == st["state"]
+    assert (int(s.pcg_inc[0]) << 64) | int(s.pcg_inc[1]) == st["inc"]
+    assert s.stream_offset == 12 and s.two_g == 2 * 9.81
+    assert list(s.x0_template) == list(PG.notebook_initial_state(PG.PlanarQuadruped()))
+    assert (s.theta_deg[0], s.theta_deg[1]) == PG.THETA0_DEG and (s.omega[0], s.omega[1]) == PG.OMEGA0
