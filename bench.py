@@ -243,6 +243,10 @@ def base_record(args, value, n_gpus, elapsed, batch_B, batch_N, z_stride, extra_
     }
 
 
+def alg_bytes_of(batch, structural):
+    return float(np.sum((strict_bytes if structural else algorithmic_bytes)(batch.N, batch.k_trans)))
+
+
 def roofline_record(args, batch, ms_each):
     structural = args.jac_format == "structural"
     # the bytes a launch must move: dense 15x20 blocks or, when only the structural non-zeros are
@@ -395,6 +399,24 @@ def run_ranks(args):
             assert f_all.numel() == batch.B * world and viol_all.numel() == batch.B * world
             out["gather_ms"] = t_gather * 1e3        # f + constraint violation, inside the timed region
             out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank), outside it
+        if world == 1 and not args.no_other:
+            # all four callbacks of an NLP iteration from one read of Z in one launch (qln_eval_all): same workload, same buffers
+            gg = nlp.new_Z()
+            for _ in range(3):
+                nlp.eval_all(Z, f, gg, c, vals, write_constants=False)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+            for a, b_ in ev:
+                a.record()
+                nlp.eval_all(Z, f, gg, c, vals, write_constants=False)
+                b_.record()
+            torch.cuda.synchronize()
+            ms_all = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+            all_bytes = alg_bytes_of(batch, structural) + 8.0 * nlp.n_nlp * batch.B
+            out.setdefault("other", {})["eval_all_one_launch"] = {
+                "launch_ms_avg": ms_all, "achieved_GBs": all_bytes / (ms_all * 1e-3) / 1e9,
+                "roofline_frac": all_bytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "qln_eval_all: eval_f + grad_f! + eval_c! + jac_c! from one read of Z; bytes = the hot launch's + the gradient written"}
+            del gg
         if world == 1 and not args.no_other and not structural:
             # same workload, structural format (only the non-zeros of every step block are written)
             del vals

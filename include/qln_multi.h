@@ -98,6 +98,13 @@ int qln_multi_alloc_vals(qln_multi* m, int placed);
 int qln_multi_eval_constraint_and_jacobian(qln_multi* m, int with_jacobian, uint32_t flags);
 int qln_multi_eval_objective(qln_multi* m);         /* -> every shard's f    */
 int qln_multi_constraint_violation(qln_multi* m);   /* -> every shard's viol (from its c) */
+/* qln_solve on every shard, in place on the shard's Z (qln_multi_set_Z / qln_multi_initial_guess); launched on all
+ * devices before anything is waited for.  Afterwards qln_multi_eval_objective + qln_multi_eval_constraint_and_jacobian(0) +
+ * qln_multi_constraint_violation give the evaluator's verdict on the solutions, and qln_multi_gather brings it to the root:
+ * the end-of-job gather then carries final results.  opt: NULL = defaults.  info: per-shard device buffers are owned by m;
+ * qln_multi_solve_info copies them to the host ([B][QLN_SOLVE_INFO_STRIDE], global problem order). */
+int qln_multi_solve(qln_multi* m, const qln_solve_options* opt);
+int qln_multi_solve_info(qln_multi* m, double* info_host);
 int qln_multi_synchronize(qln_multi* m);
 /* The end-of-job exchange: per-problem results of every shard to device `root_shard`'s gather buffers (allocated on
  * first use), over RCCL.  `what` = QLN_GATHER_* bits.  Stream-ordered after the evaluations. */

@@ -51,7 +51,7 @@ struct qln_multi {
         qln_handle* h = nullptr;
         hipStream_t stream = nullptr;
         qln_dims dims{};
-        double *Z = nullptr, *c = nullptr, *vals = nullptr, *f = nullptr, *viol = nullptr;
+        double *Z = nullptr, *c = nullptr, *vals = nullptr, *f = nullptr, *viol = nullptr, *sinfo = nullptr;
         bool vals_placed = false;
         int64_t c_displ = 0;  // where the shard's constraint vector starts in the gathered one
     };
@@ -208,7 +208,7 @@ int qln_multi_destroy(qln_multi* m) {
     for (auto& s : m->shards) {
         (void)hipSetDevice(s.device);
         if (s.vals && !s.vals_placed) (void)hipFree(s.vals);  // placed buffers are released by qln_destroy
-        for (double* p : {s.Z, s.c, s.f, s.viol})
+        for (double* p : {s.Z, s.c, s.f, s.viol, s.sinfo})
             if (p) (void)hipFree(p);
         if (s.h)
             if (int r = qln_destroy(s.h); r != QLN_OK && rc == QLN_OK) rc = r;
@@ -380,6 +380,30 @@ int qln_multi_eval_objective(qln_multi* m) {
 int qln_multi_constraint_violation(qln_multi* m) {
     if (!m) return fail(QLN_ERR_INVALID_ARGUMENT, "null handle");
     for (auto& s : m->shards) QM_OK(qln_constraint_violation(s.h, s.c, s.viol));
+    return QLN_OK;
+}
+
+int qln_multi_solve(qln_multi* m, const qln_solve_options* opt) {
+    if (!m) return fail(QLN_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto& s : m->shards) {
+        if (!s.sinfo) {
+            QM_HIP(hipSetDevice(s.device));
+            QM_HIP(hipMalloc(reinterpret_cast<void**>(&s.sinfo), (size_t)s.dims.B * QLN_SOLVE_INFO_STRIDE * sizeof(double)));
+        }
+        QM_OK(qln_solve(s.h, s.Z, opt, s.sinfo));
+    }
+    return QLN_OK;
+}
+
+int qln_multi_solve_info(qln_multi* m, double* info_host) {
+    if (!m || !info_host) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_solve_info: null argument");
+    for (auto& s : m->shards) {
+        if (!s.sinfo) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_solve_info: qln_multi_solve has not run");
+        QM_HIP(hipSetDevice(s.device));
+        QM_HIP(hipStreamSynchronize(s.stream));
+        QM_HIP(hipMemcpy(info_host + s.lo * QLN_SOLVE_INFO_STRIDE, s.sinfo, (size_t)s.dims.B * QLN_SOLVE_INFO_STRIDE * sizeof(double),
+                         hipMemcpyDeviceToHost));
+    }
     return QLN_OK;
 }
 

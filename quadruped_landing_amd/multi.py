@@ -50,6 +50,8 @@ SIGNATURES = {
     "qln_multi_eval_constraint_and_jacobian": (C.c_int, [_vp, C.c_int, C.c_uint32]),
     "qln_multi_eval_objective": (C.c_int, [_vp]),
     "qln_multi_constraint_violation": (C.c_int, [_vp]),
+    "qln_multi_solve": (C.c_int, [_vp, C.POINTER(_lib.QlnSolveOptions)]),
+    "qln_multi_solve_info": (C.c_int, [_vp, _vp]),
     "qln_multi_synchronize": (C.c_int, [_vp]),
     "qln_multi_gather": (C.c_int, [_vp, C.c_uint32, C.c_int]),
     "qln_multi_gathered_to_host": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -229,6 +231,19 @@ class MultiNLP:
 
     def constraint_violation(self):
         _lib.check(lib().qln_multi_constraint_violation(self._h))
+
+    def solve(self, **options):
+        """qln_solve on every shard, in place on the shards' Z; returns the (B, 16) info array (global problem order)."""
+        opt = _lib.QlnSolveOptions()
+        _lib.check(_lib.lib().qln_solve_default_options(C.byref(opt)))
+        for k, v in options.items():
+            if not hasattr(opt, k):
+                raise TypeError(f"unknown solve option {k!r}")
+            setattr(opt, k, v)
+        _lib.check(lib().qln_multi_solve(self._h, C.byref(opt)))
+        info = np.zeros((self.B, _lib.SOLVE_INFO_STRIDE))
+        _lib.check(lib().qln_multi_solve_info(self._h, info.ctypes.data))
+        return info
 
     def synchronize(self):
         _lib.check(lib().qln_multi_synchronize(self._h))

@@ -85,3 +85,29 @@ def test_one_process_per_gpu_communicator_with_the_ranks_that_fit_on_this_box():
     assert comm.max(3.25) == 3.25
     comm.barrier()
     comm.close()
+
+
+def test_sharded_solve_and_the_gather_of_final_results():
+    """The whole north-star job through the multi-GPU layer: the batch is sharded, every shard's problems are SOLVED where
+    they live (qln_multi_solve), the evaluator judges the solutions per shard, and the one RCCL gather at the end brings
+    objective and constraint violation of every problem to the root."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, multi, problem_gen as PG
+
+    ndev = torch.cuda.device_count()
+    batch = PG.make_batch(48, 40, 14, 1, seed=21, noise=0.0)
+    m = multi.MultiNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf, devices=list(range(ndev)))
+    m.initial_guess()
+    info = m.solve()
+    m.eval_c_and_jac(with_jacobian=False)
+    m.eval_f()
+    m.constraint_violation()
+    m.gather(multi.GATHER_F | multi.GATHER_VIOL)
+    f, viol, _ = m.gathered()
+    assert (info[:, 5] == 0).all() and viol.max() <= 1e-6 * 1.0001
+    assert np.allclose(f, info[:, 2], rtol=1e-12, atol=0)
+    # the same problems through a single handle give the same bits
+    one = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z1, info1 = one.solve(one.initial_guess())
+    assert np.array_equal(one.eval_f(Z1).cpu().numpy(), f)
+    m.close()
