@@ -189,7 +189,7 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * info (device, may be NULL): QLN_SOLVE_INFO_STRIDE doubles per problem {outer iterations, iLQR iterations, objective
  * f of the returned Z, constraint violation (the solver's measure: the rows and bounds it penalises), final penalty
  * rho, status (0 = converged to tol_violation, 1 = iteration limit, 2 = no descent at the largest penalty),
- * augmented cost, last accepted step length, sum of h, LM mu at exit, 0...}.
+ * augmented cost, last accepted step length, sum of h, LM mu at exit, five phase timers, 1 if the rescue phase ran}.
  * There is no reference oracle for the iterates (the reference hands its callbacks to Ipopt); the result is judged by
  * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
  * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~400).  Stream-ordered. */
@@ -208,6 +208,9 @@ typedef struct qln_solve_options {
     double h_prox;            /* proximal weight on the step lengths in the Newton system (it vanishes at a fixed point):
                                  with the reference's gradient the objective does not see h, the h_k are fixed by the
                                  constraints alone and wander along flat directions without it          default 1e4 */
+    int32_t rescue_outer;     /* a problem still above the tolerance after max_outer updates gets this many more, with
+                                 accurate inner solves (60 iterations) from a penalty of at most 1e6; info[15] = 1
+                                 where that phase ran                                                     default 20 */
 } qln_solve_options;
 #define QLN_SOLVE_INFO_STRIDE 16
 int qln_solve_default_options(qln_solve_options* opt);

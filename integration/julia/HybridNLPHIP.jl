@@ -96,6 +96,7 @@ struct QlnSolveOptions
     h_min::Cdouble; h_max::Cdouble; theta_min::Cdouble; theta_max::Cdouble
     q6_bounds::Int32; exact_h_gradient::Int32
     h_prox::Cdouble
+    rescue_outer::Int32
 end
 
 function solve_hip(x0, prob::HybridNLPHIP; c_tol=1.0e-6)
@@ -103,7 +104,7 @@ function solve_hip(x0, prob::HybridNLPHIP; c_tol=1.0e-6)
     qln_check(ccall((:qln_solve_default_options, LIBQLN), Cint, (Ref{QlnSolveOptions},), opt))
     o = opt[]
     opt[] = QlnSolveOptions(o.max_outer, o.max_inner, c_tol, o.inner_tol, o.rho0, o.rho_factor, o.rho_max, o.h_min, o.h_max,
-                            o.theta_min, o.theta_max, o.q6_bounds, o.exact_h_gradient, o.h_prox)
+                            o.theta_min, o.theta_max, o.q6_bounds, o.exact_h_gradient, o.h_prox, o.rescue_outer)
     Z = collect(Float64, x0)             # in: initial guess (its controls are used); out: the solution
     info = zeros(16)                     # {outer, iLQR iterations, f, violation, rho, status, ...}
     qln_check(ccall((:qln_solve_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{QlnSolveOptions}, Ptr{Cdouble}),

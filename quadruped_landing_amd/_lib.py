@@ -77,6 +77,7 @@ class QlnSolveOptions(C.Structure):
         ("q6_bounds", C.c_int32),
         ("exact_h_gradient", C.c_int32),
         ("h_prox", C.c_double),
+        ("rescue_outer", C.c_int32),
     ]
 
 

@@ -614,6 +614,7 @@ int qln_solve_default_options(qln_solve_options* o) {
     o->q6_bounds = 1;
     o->exact_h_gradient = 0;
     o->h_prox = 1e4;
+    o->rescue_outer = 20;
     return QLN_OK;
 }
 
@@ -626,7 +627,7 @@ int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt, double* in
     if (opt) o = *opt;
     if (o.max_outer < 0 || o.max_inner < 1 || !(o.tol_violation > 0) || !(o.rho0 > 0) || !(o.rho_factor > 1) || !(o.rho_max >= o.rho0) ||
         !(o.h_min > 0) || !(o.h_max >= o.h_min) || !(o.theta_max > o.theta_min) || !(o.inner_tol >= 0) ||
-        !(o.h_prox >= 0))
+        !(o.h_prox >= 0) || o.rescue_outer < 0)
         return fail(QLN_ERR_INVALID_ARGUMENT, "qln_solve: bad options");
     if (qln::ilqr_lds_bytes(h->dims.N) > 160 * 1024)
         return fail(QLN_ERR_UNSUPPORTED, "qln_solve: N = " + std::to_string(h->dims.N) + " does not fit one problem in the 160 KB of LDS of a CU");
@@ -660,6 +661,7 @@ int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt, double* in
     sp.h_prox = o.h_prox;
     sp.q6 = o.q6_bounds;
     sp.exact_h = o.exact_h_gradient;
+    sp.rescue_outer = o.rescue_outer;
     QLN_HIP(qln::launch_al_ilqr(h->p, sp, Z, info, h->solve_scratch, h->stream));
     return QLN_OK;
 }

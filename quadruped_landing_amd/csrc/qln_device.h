@@ -163,6 +163,7 @@ struct SolveParams {
     double h_prox;  // proximal weight on the step lengths in Quu: without the d(h l)/dh term (quirk Q2) the objective does
                     // not see h at all, the h_k are then fixed by the constraints alone and wander along flat directions
     int32_t q6, exact_h;
+    int32_t rescue_outer;  // extra multiplier updates with accurate inner solves for problems the schedule did not finish
 };
 size_t ilqr_lds_bytes(int32_t N);
 size_t ilqr_scratch_doubles(int32_t B, int32_t N);
