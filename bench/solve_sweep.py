@@ -13,7 +13,7 @@ batch = PG.make_batch(B, N, kt, 1, seed=3, noise=0.0)
 nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
 Z0 = nlp.initial_guess()
 torch.cuda.synchronize()
-sets = [dict(), dict(rescue_outer=0), dict(exact_h_gradient=1, max_inner=30, max_outer=40)]
+sets = [dict()]
 for opts in sets:
     Z = Z0.clone()
     torch.cuda.synchronize()
