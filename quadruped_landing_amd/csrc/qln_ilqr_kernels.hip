@@ -154,6 +154,51 @@ __device__ __forceinline__ void step_forward(const BatchParams& P, int k, int kt
     }
 }
 
+// The same knot in closed form, for the TRIAL roll-outs.  With zero-order-hold forces every acceleration but the body's
+// angular one is constant over the step, and RK4 reproduces p+ = p + h v + h^2 a/2, v+ = v + h a, and the cubic / quartic
+// in h for omega / theta (file header of qln_kernels.hip) up to rounding: 1.3e-15 against the RK4 step on random states.
+// ~70 flops instead of ~400, reciprocals instead of divisions.  The trajectory handed back to the caller is rolled out once
+// more with the evaluator's RK4 step at the very end, so that its dynamics rows are still zero to the last bit.
+struct FastStep {
+    double imb, imf, iIb, g;
+};
+__device__ __forceinline__ void step_fast(const FastStep& C, int k, int kt, int im, const double (&x)[15], const double (&u)[5],
+                                          double (&xn)[15]) {
+    const int K = k + 1;
+    const int mode = (K <= kt - 1) ? im : 3;
+    const bool jump = (K == kt - 1);
+    const double m1 = (mode == 2) ? 1.0 : 0.0, m2 = (mode == 1) ? 1.0 : 0.0;
+    const double h = u[4], h2 = h * h, hh2 = 0.5 * h2, h3_6 = h2 * h * (1.0 / 6.0), h4_24 = h2 * h2 * (1.0 / 24.0);
+    const double abx = (u[0] + u[2]) * C.imb, aby = (u[1] + u[3]) * C.imb + C.g;
+    const double a1x = m1 * (-u[0] * C.imf), a1y = m1 * (-u[1] * C.imf + C.g);
+    const double a2x = m2 * (-u[2] * C.imf), a2y = m2 * (-u[3] * C.imf + C.g);
+    const double r1x = x[3] - x[0], r1y = x[4] - x[1], r2x = x[5] - x[0], r2y = x[6] - x[1];
+    const double w1x = m1 * x[10] - x[7], w1y = m1 * x[11] - x[8], w2x = m2 * x[12] - x[7], w2y = m2 * x[13] - x[8];
+    const double tau0 = r1x * u[1] - r1y * u[0] + r2x * u[3] - r2y * u[2];
+    const double tauv = w1x * u[1] - w1y * u[0] + w2x * u[3] - w2y * u[2];
+    const double taua = C.g * ((1.0 - m1) * u[0] + (1.0 - m2) * u[2]);
+    xn[0] = x[0] + h * x[7] + hh2 * abx;
+    xn[1] = x[1] + h * x[8] + hh2 * aby;
+    xn[2] = x[2] + h * x[9] + C.iIb * (hh2 * tau0 + h3_6 * tauv + h4_24 * taua);
+    xn[3] = x[3] + m1 * (h * x[10]) + hh2 * a1x;
+    xn[4] = x[4] + m1 * (h * x[11]) + hh2 * a1y;
+    xn[5] = x[5] + m2 * (h * x[12]) + hh2 * a2x;
+    xn[6] = x[6] + m2 * (h * x[13]) + hh2 * a2y;
+    xn[7] = x[7] + h * abx;
+    xn[8] = x[8] + h * aby;
+    xn[9] = x[9] + C.iIb * (h * tau0 + hh2 * tauv + h3_6 * taua);
+    xn[10] = x[10] + h * a1x;
+    xn[11] = x[11] + h * a1y;
+    xn[12] = x[12] + h * a2x;
+    xn[13] = x[13] + h * a2y;
+    xn[14] = x[14] + h;
+    if (jump) {
+        xn[4] = 0.0;
+        xn[6] = 0.0;
+        xn[10] = xn[11] = xn[12] = xn[13] = 0.0;
+    }
+}
+
 // Structure of a step block that the Riccati sweep relies on (checked against the union pattern of qln_device.h):
 //   d x+/d x (15x15): the diagonal, rows 2 (theta) and 9 (omega), and (c-7, c) for c in {7, 8, 10, 11, 12, 13}
 //                     (a position picks up h times its velocity);
@@ -254,6 +299,8 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     const double Ib = P.mb * (P.lb * P.lb) / 12;
     const double mbg = P.mb * P.g;
     const double p_lb = P.lb;
+    FastStep FS;
+    FS.imb = 1.0 / P.mb, FS.imf = 1.0 / P.mf, FS.iIb = 1.0 / Ib, FS.g = P.g;
     const double h_lo = S.h_lo, h_hi = S.h_hi, th_lo = S.th_lo, th_hi = S.th_hi, h_prox = S.h_prox;
     const double mu0 = S.mu0, mu_min = S.mu_min, mu_max = S.mu_max, tol = S.tol, inner_tol = S.inner_tol;
     const double rho_factor = S.rho_factor, rho_max = S.rho_max;
@@ -764,7 +811,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     J += o.val;
 #pragma unroll
                     for (int j = 0; j < 5; ++j) tz[20 * k + 15 + j] = u[j];
-                    step_forward(P, k, kt, im, Ib, x, u, xn);
+                    step_fast(FS, k, kt, im, x, u, xn);
 #pragma unroll
                     for (int i = 0; i < 15; ++i) {
                         x[i] = xn[i];
@@ -843,7 +890,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
         if (stalled && rho >= rho_max) status = 2;
     }
 
-    // ---- write the solution (states of the roll-out: their dynamics rows are exactly zero) and the report ----
+    // ---- write the solution (k_exact_rollout then replaces the states by the RK4 roll-out of these controls) and the report ----
     for (int i = lane; i < 20 * (N - 1); i += kWave) {
         const int k = i / 20, j = i - 20 * k;
         Zb[i] = (j < 15) ? L.X[15 * k + j] : L.U[5 * k + (j - 15)];
@@ -884,6 +931,35 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     }
 }
 
+// The states handed back to the caller: the solution's controls rolled out from x0 once more with the evaluator's RK4 step
+// (the iterations above roll out in closed form, 1e-15 away), so that initial-condition, dynamics and contact rows of the
+// returned Z are zero to the last bit when the evaluator looks at them.  One thread per problem; a kernel of its own so
+// that the solver kernel's register allocation is not disturbed (with this loop inside it the sweep ran 27 % slower).
+__global__ __launch_bounds__(kWave) void k_exact_rollout(BatchParams P, double* __restrict__ Zio) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const ProblemDesc pd = P.desc[b];
+    const double Ib = P.mb * (P.lb * P.lb) / 12;
+    double* __restrict__ Zb = Zio + (int64_t)b * P.z_stride;
+    const double* __restrict__ x0g = P.bnd + (int64_t)b * 30;
+    double x[15], u[5], xn[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+        x[i] = x0g[i];
+        Zb[i] = x[i];
+    }
+    for (int k = 0; k < P.N - 1; ++k) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) u[j] = Zb[20 * k + 15 + j];
+        step_forward(P, k, pd.k_trans, pd.init_mode, Ib, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            x[i] = xn[i];
+            Zb[20 * (k + 1) + i] = xn[i];
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z, double* info, double* scratch, hipStream_t stream) {
@@ -891,6 +967,8 @@ hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_al_ilqr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_al_ilqr, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, s, Z, info, scratch);
+    if (hipError_t e2 = hipGetLastError(); e2 != hipSuccess) return e2;
+    hipLaunchKernelGGL(k_exact_rollout, dim3((p.B + kWave - 1) / kWave), dim3(kWave), 0, stream, p, Z);
     return hipGetLastError();
 }
 
