@@ -192,7 +192,7 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * augmented cost, last accepted step length, sum of h, LM mu at exit, five phase timers, 1 if the rescue phase ran}.
  * There is no reference oracle for the iterates (the reference hands its callbacks to Ipopt); the result is judged by
  * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
- * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~400).  Stream-ordered. */
+ * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~650).  Stream-ordered. */
 typedef struct qln_solve_options {
     int32_t max_outer;        /* multiplier updates                                   default 80   */
     int32_t max_inner;        /* iLQR iterations per multiplier update (inexact inner solves pay)   default 8 */

@@ -29,18 +29,35 @@
 namespace qln {
 namespace {
 
+constexpr int kCUs = 256;                  // MI355X
+constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr int kAlphas = 16;    // step lengths tried per iteration: 2^0 .. 2^-15
 constexpr int kIneq = 6;       // inequality rows per knot
 constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85 used)
-constexpr int kKn = 16;        // per-knot scalars kept in LDS
-constexpr int kKg = 80;        // doubles per knot of the feedback gains in the scratch (5 rows of 15, padded to 16)
+constexpr int kKn = 9;         // per-knot scalars kept in LDS
+constexpr int kKg = 80;        // doubles per knot of the feedback law in the scratch: 5 rows of [15 gains, feed-forward]
 
 // per-knot scalars (lane = knot phase -> backward sweep)
-enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g) */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8, KN_A0 = 9 /* a0..a5 active */, KN_TFC = 15 };
+enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g); the row is active where t > 0 */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8 };
+// (the final-control row's lam + rho e lives in leq[15])
 
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ double act(double t) { return t > 0 ? 1.0 : 0.0; }
+// sum over the four lanes of a quad (all four active), the same bits in each of them
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_quad_perm<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v += dpp_quad_perm<0x4E>(v);  // quad_perm [2, 3, 0, 1]
     return v;
 }
 __device__ __forceinline__ double wmax(double v) {
@@ -51,7 +68,7 @@ __device__ __forceinline__ double wmax(double v) {
 
 struct StageIn {
     const double* rec;   // cost record [41] (global, wave-uniform address)
-    const double* lam5;  // inequality multipliers of the knot (LDS)
+    const double* lam5;  // inequality multipliers of the knot (global scratch)
     double rho, w;       // penalty, weight on the stage cost (h_k, frozen h_k, or 1 for the terminal knot)
     bool has_u;          // k < N-1
     bool ineq;           // k >= 1: the knot's inequalities are live (x_1 = x0 is data)
@@ -229,7 +246,7 @@ constexpr bool step_structure_ok() {
 static_assert(step_structure_ok(), "the sparse products of the Riccati sweep cover every possible non-zero of a step block");
 
 struct Lds {
-    double *X, *U, *K, *D, *lam, *leq, *kn, *P, *pv, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *Qx, *Qu, *g, *Hd;
+    double *X, *U, *K, *leq, *kn, *P, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *g, *Hd;
     int* map;  // union-pattern position -> offset in [A | B]
 };
 
@@ -247,26 +264,22 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
 #define QLN_TAKE(field, n)                 \
     t.field = base ? base + off : nullptr; \
     off += (size_t)(((n) + 1) & ~1);
+    // the sweep's matrices first (compile-time offsets), row stride 16 -- see the sweep
+    QLN_TAKE(P, 240)
+    QLN_TAKE(A, 300)  // A (15x15, stride 15) then B (15x5)
+    t.B = t.A ? t.A + 225 : nullptr;
+    QLN_TAKE(T, 240)  // [T | pv]
+    QLN_TAKE(S, 80)
+    t.K = t.S;  // gains of the knot being swept, 5 rows of 16 (S is dead once Quu is formed); all knots: global scratch
+    QLN_TAKE(Qxx, 240)  // [Qxx | Qx]
+    QLN_TAKE(Qux, 80)   // [Qux | Qu]
+    QLN_TAKE(Quu, 26)
+    QLN_TAKE(g, 20)
+    QLN_TAKE(Hd, 20)
     QLN_TAKE(X, 15 * N)
     QLN_TAKE(U, 5 * N)
-    QLN_TAKE(K, 80)   // gains of the knot being swept; all knots: global scratch
-    QLN_TAKE(D, 5 * N)
-    QLN_TAKE(lam, kIneq * N)
     QLN_TAKE(leq, 16)
     QLN_TAKE(kn, kKn * N)
-    QLN_TAKE(P, 225)
-    QLN_TAKE(pv, 16)
-    QLN_TAKE(A, 300)  // A (15x15) then B (15x5)
-    t.B = t.A ? t.A + 225 : nullptr;
-    QLN_TAKE(T, 225)
-    QLN_TAKE(S, 75)
-    QLN_TAKE(Qxx, 225)
-    QLN_TAKE(Qux, 75)
-    QLN_TAKE(Quu, 32)
-    QLN_TAKE(Qx, 16)
-    QLN_TAKE(Qu, 8)
-    QLN_TAKE(g, 20)
-    QLN_TAKE(Hd, 32)
     double* mp = base ? base + off : nullptr;
     off += (size_t)((kStepUnion / 2 + 2 + 1) & ~1);
     t.map = reinterpret_cast<int*>(mp);
@@ -279,7 +292,7 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
 
 size_t ilqr_lds_bytes(int32_t N) { return carve(nullptr, N).doubles * sizeof(double); }
 // per problem: the step blocks of every knot, and one trial trajectory per step length
-size_t ilqr_scratch_doubles(int32_t B, int32_t N) { return (size_t)B * ((size_t)N * (kEnt + kKg) + (size_t)kAlphas * 20 * (size_t)N); }
+size_t ilqr_scratch_doubles(int32_t B, int32_t N) { return (size_t)B * ((size_t)N * (kEnt + kKg + kIneq) + (size_t)kAlphas * 20 * (size_t)N); }
 
 namespace {
 
@@ -287,7 +300,8 @@ namespace {
 // solver's own measure: c rows it penalises + the bounds it penalises), 4 final rho, 5 status (0 = converged to tol,
 // 1 = outer limit reached, 2 = no descent step found at the last penalty), 6 augmented cost, 7 last accepted alpha,
 // 8 sum of h, 9 LM mu at exit
-__global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams S, double* __restrict__ Zio,
+template <int OCC>
+__global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolveParams S, double* __restrict__ Zio,
                                                       double* __restrict__ info, double* __restrict__ scratch) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -308,9 +322,11 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     const bool q6 = S.q6 != 0, exact_h = S.exact_h != 0;
     const Lds L = carve(lds, N).L;
     double* __restrict__ Zb = Zio + (int64_t)b * P.z_stride;
-    double* __restrict__ ent = scratch + (int64_t)b * ((int64_t)N * (kEnt + kKg) + (int64_t)kAlphas * 20 * N);
+    double* __restrict__ ent = scratch + (int64_t)b * ((int64_t)N * (kEnt + kKg + kIneq) + (int64_t)kAlphas * 20 * N);
     double* __restrict__ Kg = ent + (int64_t)N * kEnt;    // [N][5][16]: feedback gains of every knot (L2-resident)
-    double* __restrict__ traj = Kg + (int64_t)N * kKg;    // [kAlphas][20 N]: the trial roll-outs, Z layout
+    double* __restrict__ traj = Kg + (int64_t)N * kKg;    // [20 N][kAlphas]: the trial roll-outs, entry of Z x step length
+                                                          // (the sixteen lanes of a store or load share a 128-byte line)
+    double* __restrict__ lamg = traj + (int64_t)kAlphas * 20 * N;  // [N][kIneq]: multipliers of the inequality rows
     const double* __restrict__ costg = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);  // wave-uniform reads
     const double* __restrict__ x0g = P.bnd + (int64_t)b * 30;
 
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             if (j == 4) v = fmin(fmax(v, h_lo), h_hi);
             L.U[i] = v;
         }
-        for (int i = lane; i < kIneq * N; i += kWave) L.lam[i] = 0.0;
+        for (int i = lane; i < kIneq * N; i += kWave) lamg[i] = 0.0;
         if (lane < 16) L.leq[lane] = 0.0;
         if (lane < 15) L.X[lane] = x0g[lane];
         // where the p-th entry of a step block's union pattern goes in [A | B] (the value expressions of the
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
     auto stage_in = [=](int k, double rho, double w) {
         StageIn I;
         I.rec = costg + 41 * k;
-        I.lam5 = L.lam + kIneq * k;
+        I.lam5 = lamg + kIneq * k;
         I.rho = rho;
         I.w = w;
         I.has_u = k < N - 1;
@@ -411,11 +427,10 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
 #pragma unroll
                 for (int j = 0; j < kIneq; ++j) {
                     kn[KN_T0 + j] = o.t[j];
-                    kn[KN_A0 + j] = o.t[j] > 0 ? 1.0 : 0.0;
                 }
                 kn[KN_CQ] = o.cq;
                 kn[KN_ELL] = o.ell;
-                kn[KN_TFC] = (k == N - 2) ? (L.leq[14] + rho * o.e_fc) : 0.0;
+                if (k == N - 2) L.leq[15] = L.leq[14] + rho * o.e_fc;
                 Jl += o.val;
                 vl = fmax(vl, o.viol);
             }
@@ -475,13 +490,17 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             QLN_TICK(tk_blocks);
 
             // ---- backward Riccati sweep ----
+            // LDS matrices of the sweep have a row stride of 16: an entry index splits into (row, column) by a shift and a
+            // mask, a lane keeps its column over the passes of a phase (what depends on the column only is read once),
+            // and the sixteenth column carries the vector that goes through the same product: T[:,15] = pv (so that
+            // [Qxx | Qx] = [Hxx | gx] + A'[T | pv] and [Qux | Qu] = [0 | gu] + B'[T | pv] are one loop each).
             bool pd_ok = true;
             {
                 // terminal knot: P = Hxx(N-1), pv = gx(N-1)
                 const int k = N - 1;
                 const double* kn = L.kn + kKn * k;
                 const double* rec = costg + 41 * k;
-                for (int e = lane; e < 225; e += kWave) L.P[e] = 0.0;
+                for (int e = lane; e < 240; e += kWave) L.P[e] = 0.0;
                 wave_lds_sync();
                 if (lane < 15) {
                     const int i = lane;
@@ -494,23 +513,23 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     }
                     if (i == 1) {
                         gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
-                        hi += rho * (kn[KN_A0 + 0] + kn[KN_A0 + 1] + kn[KN_A0 + 4]);
+                        hi += rho * (act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1]) + act(kn[KN_T0 + 4]));
                     }
                     if (i == 2) {
                         gi += (kn[KN_T0 + 0] - kn[KN_T0 + 1]) * kn[KN_CQ] + kn[KN_T0 + 2] - kn[KN_T0 + 3];
-                        hi += rho * ((kn[KN_A0 + 0] + kn[KN_A0 + 1]) * kn[KN_CQ] * kn[KN_CQ] + kn[KN_A0 + 2] + kn[KN_A0 + 3]);
+                        hi += rho * ((act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1])) * kn[KN_CQ] * kn[KN_CQ] + act(kn[KN_T0 + 2]) + act(kn[KN_T0 + 3]));
                     }
                     if (i == 3) {
                         gi += -kn[KN_T0 + 5];
-                        hi += rho * kn[KN_A0 + 5];
+                        hi += rho * act(kn[KN_T0 + 5]);
                     }
-                    L.pv[i] = gi;
-                    L.P[16 * i] = hi;
+                    L.T[16 * i + 15] = gi;
+                    L.P[17 * i] = hi;
                 }
                 if (lane == 0) {
-                    const double off = -rho * (kn[KN_A0 + 0] - kn[KN_A0 + 1]) * kn[KN_CQ];
-                    L.P[15 * 1 + 2] = off;
-                    L.P[15 * 2 + 1] = off;
+                    const double off = -rho * (act(kn[KN_T0 + 0]) - act(kn[KN_T0 + 1])) * kn[KN_CQ];
+                    L.P[16 * 1 + 2] = off;
+                    L.P[16 * 2 + 1] = off;
                 }
                 wave_lds_sync();
             }
@@ -529,35 +548,39 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             };
             prefetch(N - 2, pf_e0, pf_e1, pf_D, pf_d);
             for (int k = N - 2; k >= 0 && pd_ok; --k) {
+                // the lane index, opaque to loop-invariant code motion: the LDS addresses of the phases below are a few
+                // integer operations each; hoisted out of the knot loop they would occupy (and spill) registers instead
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
                 const double* kn = L.kn + kKn * k;
                 const double w = kn[KN_W];
                 const double v0 = pf_e0, v1 = pf_e1, recD = pf_D, recd = pf_d;
                 if (k > 0) prefetch(k - 1, pf_e0, pf_e1, pf_D, pf_d);
                 // A (15x15), B (15x5) from the entries
-                L.A[L.map[lane]] = v0;
-                if (lane + 64 < kStepUnion) L.A[L.map[lane + 64]] = v1;
+                L.A[L.map[ln]] = v0;
+                if (ln + 64 < kStepUnion) L.A[L.map[ln + 64]] = v1;
                 // stage gradient (20) and the Gauss-Newton Hessian: diagonal + the (yb, theta) and (F1y, F2y) couplings
-                if (lane < 20) {
-                    const int i = lane;
+                if (ln < 20) {
+                    const int i = ln;
                     const double zi = (i < 15) ? L.X[15 * k + i] : L.U[5 * k + (i - 15)];
                     double gi = w * (recD * zi + recd);
                     double hi = w * recD;
                     if (k >= 1) {
                         if (i == 1) {
                             gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
-                            hi += rho * (kn[KN_A0 + 0] + kn[KN_A0 + 1] + kn[KN_A0 + 4]);
+                            hi += rho * (act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1]) + act(kn[KN_T0 + 4]));
                         }
                         if (i == 2) {
                             gi += (kn[KN_T0 + 0] - kn[KN_T0 + 1]) * kn[KN_CQ] + kn[KN_T0 + 2] - kn[KN_T0 + 3];
-                            hi += rho * ((kn[KN_A0 + 0] + kn[KN_A0 + 1]) * kn[KN_CQ] * kn[KN_CQ] + kn[KN_A0 + 2] + kn[KN_A0 + 3]);
+                            hi += rho * ((act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1])) * kn[KN_CQ] * kn[KN_CQ] + act(kn[KN_T0 + 2]) + act(kn[KN_T0 + 3]));
                         }
                         if (i == 3) {
                             gi += -kn[KN_T0 + 5];
-                            hi += rho * kn[KN_A0 + 5];
+                            hi += rho * act(kn[KN_T0 + 5]);
                         }
                     }
                     if (k == N - 2 && (i == 16 || i == 18)) {
-                        gi += kn[KN_TFC];
+                        gi += L.leq[15];
                         hi += rho;
                     }
                     if (exact_h && i == 19) gi += kn[KN_ELL];  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
@@ -565,96 +588,118 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                     L.Hd[i] = hi;
                 }
                 wave_lds_sync();
-                const double h12 = (k >= 1) ? -rho * (kn[KN_A0 + 0] - kn[KN_A0 + 1]) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
+                const double h12 = (k >= 1) ? -rho * (act(kn[KN_T0 + 0]) - act(kn[KN_T0 + 1])) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
                 const double hfc = (k == N - 2) ? rho : 0.0;                              // d2/d(F1y)d(F2y)
                 // The products of the sweep use the structure of the step blocks instead of dense 15-term sums (see
-                // step_structure_ok below): A = diagonal + rows 2 (theta) and 9 (omega) + the six position <- velocity
-                // couplings (c-7, c); a force column of B has six rows; only the h column of B is dense.
-                // T = P A, S = P B
-                for (int e = lane; e < 225; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;
-                    const int cp = a_coupling(c);
-                    const double p0 = L.P[e], p2 = L.P[15 * r + 2], p9 = L.P[15 * r + 9], pc = L.P[15 * r + max(cp, 0)];
-                    const double a0 = L.A[16 * c], a2 = (c == 2) ? 0.0 : L.A[30 + c], a9 = (c == 9) ? 0.0 : L.A[135 + c];
+                // step_structure_ok above): A = diagonal + rows 2 (theta) and 9 (omega) + the six position <- velocity
+                // couplings (c-7, c); a force column of B has six rows; only the h column of B is dense -- its 15-term
+                // sums are split over the four lanes of a quad (terms i = p, p+4, p+8, p+12) and added up by DPP.
+                // ---- T = P A (entry (r, c): ln keeps c, r = (ln >> 4) + 4 pass), S = P B ----
+                {
+                    const int c = ln & 15, cp = a_coupling(c);
+                    const bool cv = c < 15;
+                    const int cc = cv ? c : 0;
+                    const double a0 = L.A[16 * cc], a2 = (c == 2) ? 0.0 : L.A[30 + cc], a9 = (c == 9) ? 0.0 : L.A[135 + cc];
                     const double ac = (cp >= 0) ? L.A[15 * cp + c] : 0.0;
-                    L.T[e] = fma(pc, ac, fma(p9, a9, fma(p2, a2, p0 * a0)));
-                }
-                for (int e = lane; e < 75; e += kWave) {
-                    const int r = e / 5, j = e - 5 * r;
-                    double acc = 0.0;
-                    if (j < 4) {
-                        int rows[6];
-                        b_rows(j, rows);
+                    const int cq = max(cp, 0);
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) acc = fma(L.P[15 * r + rows[q]], L.B[5 * rows[q] + j], acc);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) acc = fma(L.P[15 * r + i], L.B[5 * i + 4], acc);
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = (ln >> 4) + 4 * it;
+                        if (r < 15 && cv) {
+                            const double* pr = L.P + 16 * r;
+                            L.T[16 * r + c] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[c] * a0)));
+                        }
                     }
-                    L.S[e] = acc;
+                }
+                if (ln < 60) {
+                    const int r = ln >> 2, j = ln & 3;
+                    const double* pr = L.P + 16 * r;
+                    int rows[6];
+                    b_rows(j, rows);
+                    double acc = 0.0, ah = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc = fma(pr[rows[q]], L.B[5 * rows[q] + j], acc);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = j + 4 * t, ic = min(i, 14);
+                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        ah = fma(pr[ic], bv, ah);
+                    }
+                    ah = quad_sum(ah);
+                    L.S[5 * r + j] = acc;
+                    if (j == 0) L.S[5 * r + 4] = ah;
                 }
                 wave_lds_sync();
-                // Qxx = Hxx + A'T, Qux = B'T, Quu = Huu + B'S + mu I, Qx = gx + A'pv, Qu = gu + B'pv
-                for (int e = lane; e < 225; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;
-                    const int rp = a_coupling(r);
-                    double acc = (r == c) ? L.Hd[r] : 0.0;
-                    if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
-                    const double a0 = L.A[16 * r], a2 = (r == 2) ? 0.0 : L.A[30 + r], a9 = (r == 9) ? 0.0 : L.A[135 + r];
-                    const double ac = (rp >= 0) ? L.A[15 * rp + r] : 0.0;
-                    acc = fma(a0, L.T[e], acc);
-                    acc = fma(a2, L.T[30 + c], acc);
-                    acc = fma(a9, L.T[135 + c], acc);
-                    acc = fma(ac, L.T[15 * max(rp, 0) + c], acc);
-                    L.Qxx[e] = acc;
-                }
-                for (int e = lane; e < 75; e += kWave) {
-                    const int j = e / 15, c = e - 15 * j;  // j: control, c: state
-                    double acc = 0.0;
-                    if (j < 4) {
-                        int rows[6];
-                        b_rows(j, rows);
+                // ---- [Qxx | Qx] = [Hxx | gx] + A'[T | pv] ----
+                {
+                    const int c = ln & 15;
+                    const double t2 = L.T[32 + c], t9 = L.T[144 + c];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[15 * rows[q] + c], acc);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + 4], L.T[15 * i + c], acc);
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = (ln >> 4) + 4 * it;
+                        if (r < 15) {
+                            const int rp = a_coupling(r);
+                            double acc = (c == 15) ? L.g[r] : ((r == c) ? L.Hd[r] : 0.0);
+                            if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
+                            const double a0 = L.A[16 * r], a2 = (r == 2) ? 0.0 : L.A[30 + r], a9 = (r == 9) ? 0.0 : L.A[135 + r];
+                            const double ac = (rp >= 0) ? L.A[15 * rp + r] : 0.0;
+                            acc = fma(a0, L.T[16 * r + c], acc);
+                            acc = fma(a2, t2, acc);
+                            acc = fma(a9, t9, acc);
+                            acc = fma(ac, L.T[16 * max(rp, 0) + c], acc);
+                            L.Qxx[16 * r + c] = acc;
+                        }
                     }
-                    L.Qux[e] = acc;
                 }
-                if (lane < 25) {
-                    const int j = lane / 5, c = lane - 5 * j;
-                    double acc = (j == c) ? L.Hd[15 + j] + mu : 0.0;
-                    if (j == 4 && c == 4) acc += h_prox;  // proximal weight on the step length (see SolveParams)
-                    if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
-                    if (j < 4) {
+                // ---- [Qux | Qu] = [0 | gu] + B'[T | pv]: force rows (ln = 16 j + c), then the h row in quads ----
+                {
+                    const int j = (ln >> 4), c = ln & 15;
+                    int rows[6];
+                    b_rows(j, rows);
+                    double acc = (c == 15) ? L.g[15 + j] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[16 * rows[q] + c], acc);
+                    L.Qux[16 * j + c] = acc;
+                }
+                {
+                    const int c = ln >> 2, p = ln & 3;
+                    double ah = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = p + 4 * t, ic = min(i, 14);
+                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        ah = fma(bv, L.T[16 * ic + c], ah);
+                    }
+                    ah = quad_sum(ah);
+                    if (p == 0) L.Qux[64 + c] = ah + ((c == 15) ? L.g[19] : 0.0);
+                }
+                // ---- Quu = Huu + B'S + mu I: the force rows (and, by symmetry, the h row), then (h, h) in a quad ----
+                if (ln < 32) {
+                    const int j = ln >> 3, c = ln & 7;
+                    if (c < 5) {
                         int rows[6];
                         b_rows(j, rows);
+                        double acc = (j == c) ? L.Hd[15 + j] + mu : 0.0;
+                        if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
 #pragma unroll
                         for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.S[5 * rows[q] + c], acc);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + 4], L.S[5 * i + c], acc);
+                        L.Quu[5 * j + c] = acc;
+                        if (c == 4) L.Quu[20 + j] = acc;
                     }
-                    L.Quu[lane] = acc;
-                } else if (lane >= 32 && lane < 47) {
-                    const int r = lane - 32;
-                    const int rp = a_coupling(r);
-                    double acc = L.g[r];
-                    acc = fma(L.A[16 * r], L.pv[r], acc);
-                    if (r != 2) acc = fma(L.A[30 + r], L.pv[2], acc);
-                    if (r != 9) acc = fma(L.A[135 + r], L.pv[9], acc);
-                    if (rp >= 0) acc = fma(L.A[15 * rp + r], L.pv[rp], acc);
-                    L.Qx[r] = acc;
-                } else if (lane >= 48 && lane < 53) {
-                    const int j = lane - 48;
-                    double acc = L.g[15 + j];
+                } else if (ln < 36) {
+                    const int p = ln & 3;
+                    double ah = 0.0;
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) acc = fma(L.B[5 * i + j], L.pv[i], acc);
-                    L.Qu[j] = acc;
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = p + 4 * t, ic = min(i, 14);
+                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        ah = fma(bv, L.S[5 * ic + 4], ah);
+                    }
+                    ah = quad_sum(ah);
+                    if (p == 0) L.Quu[24] = ah + L.Hd[19] + mu + h_prox;  // + the proximal weight on the step length (see SolveParams)
                 }
                 wave_lds_sync();
-                // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every lane alike
+                // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every ln alike
                 double q[5][5], l[5][5], dd[5], dinv[5];
 #pragma unroll
                 for (int r = 0; r < 5; ++r)
@@ -676,7 +721,7 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         l[i][j] = v * dinv[j];
                     }
                 }
-                if (!pd_ok) break;  // wave-uniform: every lane factors the same matrix
+                if (!pd_ok) break;  // wave-uniform: every ln factors the same matrix
                 // solve Quu y = rhs for the first n unknowns (n = 5, or 4 with h clamped)
                 auto ldl_solve = [&](double (&y)[5], int n) {
 #pragma unroll
@@ -698,10 +743,13 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         }
                     }
                 };
-                // feed-forward (every lane), with the box on h: clamp, then re-solve the free 4x4
-                double dff[5];
+                // feed-forward (every ln), with the box on h: clamp, then re-solve the free 4x4
+                double qu[5], dff[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) dff[i] = -L.Qu[i];
+                for (int i = 0; i < 5; ++i) {
+                    qu[i] = L.Qux[16 * i + 15];
+                    dff[i] = -qu[i];
+                }
                 ldl_solve(dff, 5);
                 const double hk = L.U[5 * k + 4];
                 const double lo = h_lo - hk, hi = h_hi - hk;
@@ -709,16 +757,16 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 if (clamped) {
                     const double hc = fmin(fmax(dff[4], lo), hi);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dff[i] = -(L.Qu[i] + q[i][4] * hc);
+                    for (int i = 0; i < 4; ++i) dff[i] = -(qu[i] + q[i][4] * hc);
                     dff[4] = 0.0;
                     ldl_solve(dff, 4);
                     dff[4] = hc;
                 }
-                // gains: lane j < 15 solves column j
+                // gains: ln j < 15 solves column j
                 double kc[5] = {0, 0, 0, 0, 0};
-                if (lane < 15) {
+                if (ln < 15) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[15 * i + lane];
+                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[16 * i + ln];
                     if (clamped) {
                         kc[4] = 0.0;
                         ldl_solve(kc, 4);
@@ -727,14 +775,11 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                         ldl_solve(kc, 5);
                     }
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        L.K[15 * i + lane] = kc[i];
-                        Kg[(int64_t)kKg * k + 16 * i + lane] = kc[i];
-                    }
+                    for (int i = 0; i < 5; ++i) L.K[16 * i + ln] = kc[i];
                 }
-                if (lane == 0) {
+                if (ln < 16) {  // row i of the knot's record: 15 gains, then the feed-forward d_i
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) L.D[5 * k + i] = dff[i];
+                    for (int i = 0; i < 5; ++i) Kg[(int64_t)kKg * k + 16 * i + ln] = (ln < 15) ? kc[i] : dff[i];
                 }
                 wave_lds_sync();
                 // Value function of the knot: with K = -Quu_ff^-1 Qux_f on the free controls (zero rows for a clamped h) and
@@ -742,22 +787,36 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
                 //     P <- sym(Qxx + Qux' K),   pv <- Qx + Qux' d
                 // -- half the products of the symmetric three-term form (measured: the same iterates to the last digit of the
                 // iteration counts on 16 384 problems).  Entry (r, c) is the mean of the expression and of its transpose,
-                // formed by the same lane and written straight into P (nothing of this phase reads P).
-                for (int e = lane; e < 225; e += kWave) {
-                    const int r = e / 15, c = e - 15 * r;
-                    double acc = L.Qxx[e], act = L.Qxx[15 * c + r];
+                // formed by the same ln and written straight into P (nothing of this phase reads P).
+                {
+                    const int c = ln & 15;
+                    const bool cv = c < 15;
+                    const int cc = cv ? c : 0;
+                    double qc[5], kcol[5];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        acc = fma(L.Qux[15 * i + r], L.K[15 * i + c], acc);
-                        act = fma(L.Qux[15 * i + c], L.K[15 * i + r], act);
+                        qc[i] = L.Qux[16 * i + cc];
+                        kcol[i] = L.K[16 * i + cc];
                     }
-                    L.P[e] = 0.5 * (acc + act);
-                }
-                if (lane < 15) {
-                    double acc = L.Qx[lane];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = fma(L.Qux[15 * i + lane], dff[i], acc);
-                    L.pv[lane] = acc;
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = (ln >> 4) + 4 * it;
+                        if (r < 15 && cv) {
+                            double acc = L.Qxx[16 * r + c], act_ = L.Qxx[16 * c + r];
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) {
+                                acc = fma(L.Qux[16 * i + r], kcol[i], acc);
+                                act_ = fma(qc[i], L.K[16 * i + r], act_);
+                            }
+                            L.P[16 * r + c] = 0.5 * (acc + act_);
+                        }
+                    }
+                }
+                if (ln < 15) {
+                    double acc = L.Qxx[16 * ln + 15];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) acc = fma(L.Qux[16 * i + ln], dff[i], acc);
+                    L.T[16 * ln + 15] = acc;
                 }
                 wave_lds_sync();
             }
@@ -772,59 +831,74 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
 
             QLN_TICK(tk_sweep);
             __threadfence();  // the gains written during the sweep are read back by the roll-out lanes
-            // ---- forward: one closed-loop roll-out per step length, lane a tries alpha = 2^-a and keeps its
-            //      trajectory in the scratch (Z layout), so that the accepted one need not be rolled out again ----
+            // ---- forward: one closed-loop roll-out per step length, lane a < 16 tries alpha = 2^-a and keeps its
+            //      trajectory in the scratch, so that the accepted one need not be rolled out again.  Only the
+            //      state recursion is serial: the gains of the next knot are fetched by all 64 lanes (coalesced) while
+            //      the sixteen roll-out lanes take their step, and handed over through LDS (T and Qxx of the sweep are
+            //      free now: 80 doubles each); the merit of the sixteen trajectories is evaluated afterwards, four
+            //      lanes per trajectory.
             double J_try = INFINITY;
-            if (lane < kAlphas) {
-                const double alpha = ldexp(1.0, -lane);
-                double* __restrict__ tz = traj + (int64_t)lane * 20 * N;
+            {
+                const int a = lane & (kAlphas - 1);
+                const double alpha = ldexp(1.0, -a);
+                double* __restrict__ tz = traj + a;
                 double x[15], u[5], xn[15];
-                double J = 0.0;
 #pragma unroll
                 for (int i = 0; i < 15; ++i) x[i] = L.X[i];
+                {
+                    const double g0 = Kg[lane], g1 = Kg[64 + a];
+                    L.T[lane] = g0;
+                    if (lane < 16) L.T[64 + lane] = g1;
+                }
+                wave_lds_sync();
                 for (int k = 0; k < N - 1; ++k) {
-                    double kg[5][16];
-                    {
-                        const double2* __restrict__ kp = reinterpret_cast<const double2*>(Kg + (int64_t)kKg * k);
+                    const double* kc = (k & 1) ? L.Qxx : L.T;
+                    double* kx = (k & 1) ? L.T : L.Qxx;
+                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 1, N - 2);
+                    const double g0 = kp[lane], g1 = kp[64 + a];
+                    if (lane < kAlphas) {
 #pragma unroll
-                        for (int j = 0; j < 5; ++j)
+                        for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * kc[16 * j + 15];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const double2 v = kp[8 * j + i];
-                                kg[j][2 * i] = v.x;
-                                kg[j][2 * i + 1] = v.y;
-                            }
+                        for (int i = 0; i < 15; ++i) {
+                            const double dx = x[i] - L.X[15 * k + i];
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) u[j] = fma(kc[16 * j + i], dx, u[j]);
+                        }
+                        u[4] = fmin(fmax(u[4], h_lo), h_hi);
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) tz[kAlphas * (20 * k + 15 + j)] = u[j];
+                        step_fast(FS, k, kt, im, x, u, xn);
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) {
+                            x[i] = xn[i];
+                            tz[kAlphas * (20 * (k + 1) + i)] = xn[i];
+                        }
                     }
+                    kx[lane] = g0;
+                    if (lane < 16) kx[64 + lane] = g1;
+                    wave_lds_sync();
+                }
+                __threadfence();  // the trajectories written by lanes < 16 are read back by all
+                // merit: lane = (trajectory a, knots k = s, s + 4, ...), the four partial sums of a trajectory then added
+                const int s4 = lane >> 4;
+                double J = 0.0;
+                for (int k = s4; k < N; k += 4) {
+                    double uk[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * L.D[5 * k + j];
+                    for (int i = 0; i < 15; ++i) x[i] = (k == 0) ? L.X[i] : __builtin_nontemporal_load(tz + kAlphas * (20 * k + i));
+                    if (k < N - 1) {
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) {
-                        const double dx = x[i] - L.X[15 * k + i];
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) u[j] = fma(kg[j][i], dx, u[j]);
+                        for (int j = 0; j < 5; ++j) uk[j] = __builtin_nontemporal_load(tz + kAlphas * (20 * k + 15 + j));
                     }
-                    u[4] = fmin(fmax(u[4], h_lo), h_hi);
-                    const double w = exact_h ? u[4] : L.kn[kKn * k + KN_W];
+                    const double w = (k < N - 1) ? (exact_h ? uk[4] : L.kn[kKn * k + KN_W]) : 1.0;
                     StageIn I = stage_in(k, rho, w);
                     StageOut o;
-                    stage_eval(I, x, u, o);
-                    J += o.val;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) tz[20 * k + 15 + j] = u[j];
-                    step_fast(FS, k, kt, im, x, u, xn);
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) {
-                        x[i] = xn[i];
-                        tz[20 * (k + 1) + i] = xn[i];
-                    }
-                }
-                {
-                    double u0[5] = {0, 0, 0, 0, 0};
-                    StageIn I = stage_in(N - 1, rho, 1.0);
-                    StageOut o;
-                    stage_eval(I, x, u0, o);
+                    stage_eval(I, x, uk, o);
                     J += o.val;
                 }
+                J += __shfl_xor(J, 16, kWave);
+                J += __shfl_xor(J, 32, kWave);
                 J_try = J;
             }
             QLN_TICK(tk_roll);
@@ -854,10 +928,10 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             __threadfence();
             wave_lds_sync();
             {
-                const double* __restrict__ tz = traj + (int64_t)a_star * 20 * N;
+                const double* __restrict__ tz = traj + a_star;
                 for (int i = 15 + lane; i < 20 * (N - 1) + 15; i += kWave) {
                     const int k = i / 20, j = i - 20 * k;
-                    const double v = __builtin_nontemporal_load(tz + i);
+                    const double v = __builtin_nontemporal_load(tz + kAlphas * i);
                     if (j < 15) L.X[15 * k + j] = v;
                     else L.U[5 * k + (j - 15)] = v;
                 }
@@ -879,11 +953,11 @@ __global__ __launch_bounds__(kWave, 1) void k_al_ilqr(BatchParams P, SolveParams
             const int k = k0 + lane;
             if (k < N && k >= 1) {
 #pragma unroll
-                for (int j = 0; j < kIneq; ++j) L.lam[kIneq * k + j] = L.kn[kKn * k + KN_T0 + j];  // max(0, lam + rho g)
+                for (int j = 0; j < kIneq; ++j) lamg[kIneq * k + j] = L.kn[kKn * k + KN_T0 + j];  // max(0, lam + rho g)
             }
         }
         if (lane < 14) L.leq[lane] += rho * (L.X[15 * (N - 1) + lane] - xf[lane]);
-        if (lane == 14) L.leq[14] = L.kn[kKn * (N - 2) + KN_TFC];
+        if (lane == 14) L.leq[14] = L.leq[15];
         wave_lds_sync();
         if (viol > 0.25 * prev_viol) rho = fmin(rho * rho_factor, rho_max);
         prev_viol = viol;
@@ -964,10 +1038,17 @@ __global__ __launch_bounds__(kWave) void k_exact_rollout(BatchParams P, double* 
 
 hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z, double* info, double* scratch, hipStream_t stream) {
     const size_t lds = ilqr_lds_bytes(p.N);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_al_ilqr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_al_ilqr, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, s, Z, info, scratch);
-    if (hipError_t e2 = hipGetLastError(); e2 != hipSuccess) return e2;
+    // Two register budgets: a batch that fills the chip more than once over runs two waves per SIMD (256 registers, a
+    // few spills outside the sweep) -- one wave keeps a SIMD's issue slots about 45 % busy, the second one fills them
+    // (profiles/r02_solve_occupancy.txt); a batch of at most one wave per SIMD gets the whole register file.
+    const bool two_per_simd = p.B > 4 * kCUs && 5 * lds <= kLdsPerCU;  // more than 4 waves per CU must fit the LDS
+    auto go = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(xcd_grid(p.B)), dim3(kWave), lds, stream, p, s, Z, info, scratch);
+        return hipGetLastError();
+    };
+    if (hipError_t e2 = two_per_simd ? go(k_al_ilqr<2>) : go(k_al_ilqr<1>); e2 != hipSuccess) return e2;
     hipLaunchKernelGGL(k_exact_rollout, dim3((p.B + kWave - 1) / kWave), dim3(kWave), 0, stream, p, Z);
     return hipGetLastError();
 }

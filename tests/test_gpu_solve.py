@@ -150,7 +150,7 @@ def test_solve_rejects_what_it_cannot_do():
         assert e.value.code == _lib.QLN_ERR_INVALID_ARGUMENT, bad
     with pytest.raises(TypeError):
         nlp.solve(Z, no_such_option=1)
-    big = PG.make_batch(1, 500, 50, 1, seed=1)  # 47 N + 1.4k doubles of LDS: N <= ~400 fits the 160 KB of a CU
+    big = PG.make_batch(1, 700, 50, 1, seed=1)  # 29 N + 1.3k doubles of LDS: N <= ~650 fits the 160 KB of a CU
     nb = HybridNLP(big.model, big.obj, big.init_mode, big.k_trans, big.N, big.x0, big.xf)
     with pytest.raises(_lib.QlnError) as e:
         nb.solve(nb.upload_Z(big.Z))
