@@ -1,5 +1,5 @@
 """Parameter sweep / timing of qln_solve on random landing problems (run on the GPU box).
-   python bench/solve_sweep.py [B] [N] [k_trans]"""
+   python bench/solve_sweep.py [B] [N] [k_trans] [full]     ("full": the option sets of profiles/r02_solve_sweep.txt as well)"""
 import sys, time
 import numpy as np
 import torch
@@ -14,6 +14,9 @@ nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N,
 Z0 = nlp.initial_guess()
 torch.cuda.synchronize()
 sets = [dict()]
+if "full" in sys.argv:
+    sets += [dict(max_outer=30, max_inner=60, rho0=1.0, rho_factor=10.0), dict(h_prox=0.0),
+             dict(exact_h_gradient=1, max_inner=30, max_outer=40)]
 for opts in sets:
     Z = Z0.clone()
     torch.cuda.synchronize()

@@ -25,6 +25,7 @@
 #include "qln_kernel_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace qln {
 namespace {
@@ -883,16 +884,30 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 // merit: lane = (trajectory a, knots k = s, s + 4, ...), the four partial sums of a trajectory then added
                 const int s4 = lane >> 4;
                 double J = 0.0;
+                // (the loads of a knot are requested one pass ahead: a pass is then as long as its arithmetic)
+                double xr[15], ur[5], lr[kIneq];
+                auto fetch = [=](int k, double (&xo)[15], double (&uo)[5], double (&lo)[kIneq]) {
+                    const int kk = min(k, N - 1);
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) xo[i] = (kk == 0) ? L.X[i] : tz[kAlphas * (20 * kk + i)];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) uo[j] = tz[kAlphas * (20 * min(kk, N - 2) + 15 + j)];
+#pragma unroll
+                    for (int j = 0; j < kIneq; ++j) lo[j] = lamg[kIneq * kk + j];
+                };
+                fetch(s4, xr, ur, lr);
                 for (int k = s4; k < N; k += 4) {
-                    double uk[5] = {0, 0, 0, 0, 0};
+                    double uk[5], lk[kIneq];
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) x[i] = (k == 0) ? L.X[i] : __builtin_nontemporal_load(tz + kAlphas * (20 * k + i));
-                    if (k < N - 1) {
+                    for (int i = 0; i < 15; ++i) x[i] = xr[i];
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) uk[j] = __builtin_nontemporal_load(tz + kAlphas * (20 * k + 15 + j));
-                    }
+                    for (int j = 0; j < 5; ++j) uk[j] = (k < N - 1) ? ur[j] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < kIneq; ++j) lk[j] = lr[j];
+                    fetch(k + 4, xr, ur, lr);
                     const double w = (k < N - 1) ? (exact_h ? uk[4] : L.kn[kKn * k + KN_W]) : 1.0;
                     StageIn I = stage_in(k, rho, w);
+                    I.lam5 = lk;
                     StageOut o;
                     stage_eval(I, x, uk, o);
                     J += o.val;
@@ -1041,7 +1056,11 @@ hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z,
     // Two register budgets: a batch that fills the chip more than once over runs two waves per SIMD (256 registers, a
     // few spills outside the sweep) -- one wave keeps a SIMD's issue slots about 45 % busy, the second one fills them
     // (profiles/r02_solve_occupancy.txt); a batch of at most one wave per SIMD gets the whole register file.
-    const bool two_per_simd = p.B > 4 * kCUs && 5 * lds <= kLdsPerCU;  // more than 4 waves per CU must fit the LDS
+    bool two_per_simd = p.B > 4 * kCUs && 5 * lds <= kLdsPerCU;  // more than 4 waves per CU must fit the LDS
+#ifdef QLN_TUNING
+    // tuning build only: QLN_ILQR_OCC=1|2 forces the register budget for A/B runs (bench/solve_sweep.py)
+    if (const char* e = getenv("QLN_ILQR_OCC")) two_per_simd = atoi(e) == 2;
+#endif
     auto go = [&](auto kern) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
