@@ -144,6 +144,49 @@ def drop_state_sampler(seed: int, model: PlanarQuadruped | None = None, stream_o
     return s
 
 
+# Left-right mirror of the planar model about the midpoint of the landed feet (x -> -lb - x, the feet trade names): the
+# dynamics, the clearance row, the costs of the notebook and reference_trajectory() are symmetric under it, the contact
+# schedule init_mode 1 <-> 2.  (Of solve()'s variable bounds only quirk Q6's "x1 >= 0" is not.)
+_MIRROR_X_FROM = np.array([0, 1, 2, 5, 6, 3, 4, 7, 8, 9, 12, 13, 10, 11, 14])
+_MIRROR_X_SIGN = np.array([-1.0, 1, -1, -1, 1, -1, 1, -1, 1, -1, -1, 1, -1, 1, 1])
+_MIRROR_U_FROM = np.array([2, 3, 0, 1, 4])
+_MIRROR_U_SIGN = np.array([-1.0, 1, -1, 1, 1])
+
+
+def mirror_states(X, lb: float):
+    """(..., 15) states -> their mirror images"""
+    Y = np.asarray(X, dtype=np.float64)[..., _MIRROR_X_FROM] * _MIRROR_X_SIGN
+    Y[..., [0, 3, 5]] -= lb
+    return Y
+
+
+def mirror_controls(U):
+    return np.asarray(U, dtype=np.float64)[..., _MIRROR_U_FROM] * _MIRROR_U_SIGN
+
+
+def mirror_Z(Z, N: int, lb: float):
+    """(B, 20N-5) decision vectors -> those of the mirrored problems"""
+    Z = np.asarray(Z, dtype=np.float64)
+    out = np.empty_like(Z)
+    pad = np.concatenate([Z, np.zeros(Z.shape[:-1] + (5,))], axis=-1).reshape(Z.shape[:-1] + (N, 20))
+    M = np.concatenate([mirror_states(pad[..., :15], lb), mirror_controls(pad[..., 15:])], axis=-1)
+    out[...] = M.reshape(Z.shape[:-1] + (20 * N,))[..., : 20 * N - 5]
+    return out
+
+
+def mirror_batch(batch: LandingBatch, dt: float = 0.009) -> LandingBatch:
+    """The mirror images of a batch of landing problems (uniform cost table): init_mode 1 <-> 2, x0 / xf / Z mirrored,
+    the cost rebuilt from reference_trajectory() of the other init_mode."""
+    lb = batch.model.lb
+    im = (3 - batch.init_mode).astype(np.int32)
+    x0, xf = mirror_states(batch.x0, lb), mirror_states(batch.xf, lb)
+    Xref, Uref = reference_trajectory(batch.model, batch.N, batch.k_trans, xf, im, dt)
+    obj = None
+    if batch.obj is not None:
+        obj = lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref, Uref) if batch.obj.ndim == 3 else lqr_objective(Q_DIAG, R_DIAG, Q_DIAG, Xref[0], Uref[0])
+    return LandingBatch(batch.model, batch.N, batch.k_trans.copy(), im, x0, xf, obj, mirror_Z(batch.Z, batch.N, lb))
+
+
 def notebook_problem(N: int = 61, k_trans: int = 21, init_mode: int = 1, dt: float = 0.009,
                      model: PlanarQuadruped | None = None) -> LandingBatch:
     """The literal notebook problem (src/main.ipynb cells 2-8) as a batch of one, Z = Z0."""
