@@ -192,3 +192,70 @@ def test_full_size_region_placed_buffer_holds_the_same_values():
     print(f"region-placed buffer: fused launch {ms:.3f} ms at setup")
     assert torch.equal(vals, v2) and torch.equal(c, c2)
     assert 0.5 < ms < 2.0
+
+
+@pytest.mark.parametrize("B,N,ragged", [(65536, 40, False), (16384, 80, True)])
+def test_gpu_jacobian_is_the_derivative_of_the_gpu_constraints(B, N, ragged):
+    """A check of the Jacobian values that does not pass through the oracle, at full size: central differences of the GPU
+    eval_c (whose values are bit-identical to the oracle's, which the notebook's printed numbers pin) along a random
+    direction against (a) the stored step blocks of the hot kernel times the direction and (b) qln_eval_constraint_jvp, for
+    every problem.  The one row where the reference's Jacobian is NOT the derivative -- the clock row of the transition
+    knot, zeroed by jump*_jacobian (quirk Q1, src/planar_quadruped.jl:262-263) -- is checked to be exactly zero instead."""
+    import torch
+
+    batch, nlp, Z = _setup(B, N, ragged, seed=5)
+    dev = Z.device
+    gen = torch.Generator(device=dev).manual_seed(3)
+    v = (torch.rand(nlp.dims.z_total, dtype=torch.float64, device=dev, generator=gen) * 2 - 1)
+    eps = 1e-6
+    fd = (nlp.eval_c(Z + eps * v) - nlp.eval_c(Z - eps * v)) / (2 * eps)
+    c, vals = nlp.eval_c_and_jac(Z)
+    jv = nlp.jac_vec(Z, v)
+    torch.cuda.synchronize()
+    c_off = torch.as_tensor(nlp.c_off, device=dev)
+    j_off = torch.as_tensor(nlp.j_off, device=dev)
+    kt = torch.as_tensor(batch.k_trans.astype(np.int64), device=dev)
+    # (a) dynamics rows from the stored blocks: block_k (15 x 20, column-major) . v[x_k, u_k] - v[x_{k+1}]
+    vz = v.view(B, -1)[:, : 20 * N - 5]
+    vk = torch.cat([vz, vz.new_zeros(B, 5)], 1).view(B, N, 20)
+    worst_a = 0.0
+    for lo in range(0, B, 8192):
+        hi = min(lo + 8192, B)
+        idx = j_off[lo:hi, None] + torch.arange(300 * (N - 1), device=dev)[None, :]
+        blocks = vals[idx].view(hi - lo, N - 1, 20, 15)
+        bv = torch.einsum("bkcr,bkc->bkr", blocks, vk[lo:hi, :-1]) - vk[lo:hi, 1:, :15]
+        ridx = c_off[lo:hi, None] + 29 + torch.arange(15 * (N - 1), device=dev)[None, :]
+        f = fd[ridx].view(hi - lo, N - 1, 15)
+        j = jv[ridx].view(hi - lo, N - 1, 15)
+        q1 = torch.zeros(hi - lo, N - 1, 15, dtype=torch.bool, device=dev)
+        kq = kt[lo:hi] - 2  # 0-based knot of the jump
+        okq = (kq >= 0) & (kq < N - 1)
+        q1[torch.nonzero(okq)[:, 0], kq[okq], 14] = True
+        # Q1: the block's row is all zeros, what is left of the row is the -1 of the -I block
+        bq = torch.nonzero(okq)[:, 0]
+        assert float(blocks[bq, kq[okq], :, 14].abs().max()) == 0.0
+        assert torch.equal(bv[q1], -vk[lo:hi, 1:, 14][q1[:, :, 14]]) and torch.equal(j[q1], bv[q1])
+        scale = 1.0 + torch.einsum("bkcr,bkc->bkr", blocks.abs(), vk[lo:hi, :-1].abs())
+        worst_a = max(worst_a, float(((bv - f).abs() / scale)[~q1].max()), float(((j - f).abs() / scale)[~q1].max()))
+    # (b) every other row of c through the product kernel
+    m = torch.as_tensor(np.array([nlp.problem_dims(0)[0]] * B if not ragged else [nlp.problem_dims(int(b))[0] for b in range(B)]), device=dev)
+    worst_b = 0.0
+    for name, start, length in (("init", 0, 15), ("term", 15, 14)):
+        ridx = c_off[:, None] + start + torch.arange(length, device=dev)[None, :]
+        worst_b = max(worst_b, float((jv[ridx] - fd[ridx]).abs().max()))
+    tail0 = 29 + 15 * (N - 1)  # contact rows, final control, clearance: to the end of the problem's c
+    maxlen = int((m - tail0).max())
+    ar = torch.arange(maxlen, device=dev)[None, :]
+    ridx = c_off[:, None] + tail0 + ar
+    live = ar < (m - tail0)[:, None]
+    # the clearance rows (the last N of a problem) are kinked at theta = 0 (|sin theta|): a knot whose theta lies within the
+    # difference step of the kink has no derivative to compare with (a few dozen of the 2.6 million knots)
+    theta = torch.cat([Z.view(B, -1)[:, : 20 * N - 5], Z.new_zeros(B, 5)], 1).view(B, N, 20)[:, :, 2]
+    clr = ar - (m - tail0 - N)[:, None]  # knot of a clearance row, negative before the group
+    near_kink = (clr >= 0) & live & (theta.gather(1, clr.clamp(0, N - 1)).abs() <= 2 * eps)
+    print(f"clearance rows skipped at the kink: {int(near_kink.sum())}")
+    live = live & ~near_kink
+    ridx = torch.where(live, ridx, c_off[:, None])
+    worst_b = max(worst_b, float(((jv[ridx] - fd[ridx]).abs() * live).max()))
+    print(f"B={B} N={N} ragged={ragged}: |J v - central difference| / (1 + |J||v|): step blocks {worst_a:.2e}; other rows (absolute) {worst_b:.2e}")
+    assert worst_a <= 1e-7 and worst_b <= 1e-7
