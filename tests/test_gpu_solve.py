@@ -179,3 +179,24 @@ def test_transition_knot_extremes():
         seg = nlp.split_c(c, b)
         assert np.all(seg[: 15] == 0.0) and np.all(seg[ci[2][0] - 1 : ci[4][1]] == 0.0), b  # init, dynamics, contact rows
     assert (inf[:, 5] == 0).sum() >= 6
+
+
+@pytest.mark.parametrize("N,kt,B", [(121, 41, 16), (600, 200, 2)])
+def test_horizons_up_to_what_a_compute_units_lds_holds(N, kt, B):
+    """N = 121 (two 64-knot chunks in every lane = knot phase) and N = 600 (143 KB of the 160 KB of LDS; N = 700 is
+    refused, see test_solve_rejects_what_it_cannot_do): solved to the tolerance, roll-out rows exact."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(B, N, kt, 1, seed=5, noise=0.0, dt=0.009 * 40 / N)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z, info = nlp.solve(nlp.initial_guess())
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    print(f"N={N}: status {inf[:, 5].astype(int).tolist()}, iLQR iterations {inf[:, 1].astype(int).tolist()}, violation max {viol.max():.2e}")
+    assert np.all(inf[:, 5] == 0) and viol.max() <= 1e-6 * 1.0001 and bviol.max() <= 1e-6
+    for b in range(B):
+        ci = nlp.cinds(b)
+        seg = nlp.split_c(c, b)
+        assert np.all(seg[:15] == 0.0) and np.all(seg[ci[2][0] - 1 : ci[4][1]] == 0.0)
