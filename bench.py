@@ -117,9 +117,13 @@ def cpu_baseline(batch, nlp, Z_dev, budget_s=12.0):
         else:
             obj = batch.obj if batch.obj.ndim == 2 else batch.obj[:nb]
         c_off = nlp.c_off[:nb] - nlp.c_off[0]
-        j_off = nlp.j_off[:nb] - nlp.j_off[0]
         c_total = int(c_off[-1] + nlp.dims.m_nlp_max + 16)
-        j_total = int(j_off[-1] + nlp.dims.nnz_max + 16)
+        # the oracle writes the dense-block value layout whatever the handle's jac_format is: its own offsets
+        N, kt = batch.N, batch.k_trans[:nb].astype(np.int64)
+        nnz = 300 * (N - 1) + N + 435 + 15 * (N - 1) + 3 * N - kt + 3
+        stride = (nnz + 15) // 16 * 16
+        j_off = np.concatenate([[0], np.cumsum(stride)[:-1]]).astype(np.int64)
+        j_total = int(j_off[-1] + stride[-1])
         t0 = time.perf_counter()
         O.batch_eval(batch.N, oracle_model(batch.model), batch.k_trans[:nb], batch.init_mode[:nb], batch.x0[:nb],
                      batch.xf[:nb], obj, Zs.reshape(-1), nlp.z_stride, c_off, j_off, c_total, j_total,
