@@ -3,22 +3,26 @@
 //
 // Method: augmented-Lagrangian iLQR.  The NLP is an optimal-control problem: the dynamics rows
 // (src/constraints.jl:6-41) tie x_{k+1} to (x_k, u_k), so the states are eliminated by rolling the controls out from
-// x0 with the evaluator's own RK4 step (the solution's dynamics / initial-condition / contact rows are then zero to
-// the last bit), and a Newton-type step on the controls is a Riccati sweep over the knots -- 15x15 / 15x5 / 5x5 blocks
-// that live in the wave's LDS.  What the roll-out does not satisfy by construction -- the terminal rows
+// x0 (the iterations with the step in closed form, the result once more with the evaluator's own RK4 step: the
+// solution's dynamics / initial-condition / contact rows are then zero to the last bit), and a Newton-type step on the
+// controls is a Riccati sweep over the knots -- 15x15 / 15x5 / 5x5 blocks that live in the wave's LDS.  What the roll-out does not satisfy by construction -- the terminal rows
 // (src/constraints.jl:150), the final-control row (:154), the clearance inequalities (:98-113) and solve()'s variable
 // bounds on theta and on the entries quirk Q6 bounds (src/moi.jl:51-67) -- carries multipliers and a quadratic penalty;
 // the bounds on the step length h (a control) are kept inside the sweep (clamped feed-forward, gain row zeroed).
-//   outer loop  : multipliers  lam <- max(0, lam + rho g)  /  lam + rho e ;  rho x10 while the violation stalls
+//   outer loop  : multipliers  lam <- max(0, lam + rho g)  /  lam + rho e ;  rho x rho_factor while the violation stalls
 //   inner loop  : backward Riccati sweep with Levenberg-Marquardt mu on Quu, Gauss-Newton Hessian of the penalty terms;
-//                 forward: ALL step lengths alpha = 1, 1/2, ... tried at once, one lane per alpha, closed-loop
-//                 roll-outs; Armijo on the augmented cost.
+//                 forward: sixteen step lengths alpha = 1, 1/2, ... 2^-15 tried at once, one lane per alpha, closed-loop
+//                 roll-outs; the one with the lowest augmented cost is taken if it lowers it (a few per multiplier
+//                 update: inexact inner solves).
 // Objective gradient: by default the reference's own grad_f! (src/costs.jl:23-34), which has no d(h_k l_k)/dh_k
 // (quirk Q2): within an iteration the stage weights h_k are frozen -- the fixed point is the kind of point Ipopt's
 // run tends to with that gradient.  exact_h adds the missing term (a stationary point of the true objective).
 //
 // The step Jacobians A_k, B_k are the closed-form blocks of the evaluator (QLN_STEP_BASE / QLN_STEP_ENTRIES), derived
-// once per sweep by lane = knot and parked in a global scratch (L2-resident: 85 doubles per knot).
+// once per sweep by lane = knot and parked in a global scratch.  Per problem that scratch holds the step entries
+// (88 N doubles), the feedback law of every knot (80 N), the sixteen trial trajectories (320 N) and the inequality
+// multipliers (6 N); the wave's LDS holds the current trajectory, 9 scalars per knot and the sweep's matrices
+// (29 N + 1.3 k doubles: 19.8 KB at N = 40, eight waves per CU).
 //
 // The reference holds nothing to compare the iterates with (it hands its callbacks to Ipopt 3.13 + MUMPS); the result
 // is checked by the evaluator itself: constraint violation and objective of the returned Z (tests/test_gpu_solve.py).
