@@ -230,6 +230,20 @@ int qln_solve_host(qln_handle* h, double* Z, const qln_solve_options* opt, doubl
  * (tests/test_gpu_kinematic.py).  d: [B][2N] doubles, jac (may be NULL): [B][2N][4].  Device pointers, stream-ordered. */
 int qln_eval_kinematic_constraint(qln_handle* h, const double* Z, double* d, double* jac);
 int qln_kinematic_bounds(const qln_handle* h, double* lower, double* upper); /* the two scalars */
+/* OPT-IN EXTENSION WITHOUT A REFERENCE ORACLE.  The reference has no friction constraint at all (its NLP lets the ground
+ * pull on a foot); the path's stated scope names one, so it is offered as a group of its own, NOT part of c / vals above:
+ * the friction pyramid |F_x| <= mu F_y of every foot that stands on the ground during dynamics knot k = 0..N-2, as two
+ * linear rows per foot
+ *   d[b][4k + 0] = mu F1y_k - F1x_k,  d[b][4k + 1] = mu F1y_k + F1x_k,  d[b][4k + 2], [4k + 3]: the same for foot 2,
+ *   bounds 0 <= d < +inf (the two rows of a foot add up to 2 mu F_y >= 0: the ground only pushes).
+ * Which feet stand is the mode schedule of the dynamics rows (src/constraints.jl:23-37): before the transition knot only
+ * the foot of init_mode, from it on both; the rows of a foot in flight are 0 with zero derivatives (its force entries
+ * drive the leg, src/planar_quadruped.jl:36-79).
+ *   jac[b][4k + i][2] = d(row)/d(F_x, F_y) of that foot = (-1, mu) / (+1, mu), in the columns 20k + 15 + {0, 1} (foot 1) /
+ *   20k + 15 + {2, 3} (foot 2) of Z.
+ * Checked against a numpy statement of the same formula (tests/test_gpu_kinematic.py).  d: [B][4(N-1)] doubles, jac (may be
+ * NULL): [B][4(N-1)][2].  Device pointers, stream-ordered. */
+int qln_eval_friction_cone(qln_handle* h, const double* Z, double mu, double* d, double* jac);
 /* viol[b] = largest violation of problem b's constraint bounds (src/nlp.jl:66-69) by c: max |c_i| over the equality
  * rows, max(0, -c_i) over the clearance rows -- the "Constraint violation" Ipopt prints for the reference's solve
  * (src/main.ipynb:712).  Device pointers; c as written by qln_eval_constraint. */

@@ -136,6 +136,7 @@ SIGNATURES = {
     "qln_gauss_newton_step": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "qln_eval_kinematic_constraint": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_kinematic_bounds": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "qln_eval_friction_cone": (C.c_int, [_vp, _dp, C.c_double, _dp, _dp]),
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
     "qln_solve_default_options": (C.c_int, [C.POINTER(QlnSolveOptions)]),
     "qln_solve": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),

@@ -558,6 +558,15 @@ int qln_kinematic_bounds(const qln_handle* h, double* lower, double* upper) {
     return QLN_OK;
 }
 
+int qln_eval_friction_cone(qln_handle* h, const double* Z, double mu, double* d, double* jac) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !d) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_friction_cone: null pointer");
+    if (!(mu > 0.0) || !std::isfinite(mu)) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_friction_cone: mu must be positive and finite");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_friction_rows(h->p, Z, mu, d, jac, h->stream));
+    return QLN_OK;
+}
+
 int qln_constraint_violation(qln_handle* h, const double* c, double* viol) {
     if (int rc = check_handle(h)) return rc;
     if (!c || !viol) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_constraint_violation: null pointer");

@@ -864,6 +864,30 @@ __global__ __launch_bounds__(256) void k_kinematic_rows(BatchParams P, const dou
     }
 }
 
+// Opt-in friction pyramid |F_x| <= mu F_y of the feet that stand on the ground (qln_eval_friction_cone): one thread per
+// (problem, dynamics knot).  Which feet stand is the mode schedule of the dynamics rows (src/constraints.jl:23-37).
+__global__ __launch_bounds__(256) void k_friction_rows(BatchParams P, const double* __restrict__ Z, double mu,
+                                                      double* __restrict__ D, double* __restrict__ JV) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk = P.N - 1;
+    if (t >= (int64_t)P.B * nk) return;
+    const int b = (int)(t / nk), k = (int)(t - (int64_t)b * nk);
+    const ProblemDesc pd = P.desc[b];
+    const int mode = (k + 1 <= pd.k_trans - 1) ? pd.init_mode : 3;
+    const bool on1 = mode != 2, on2 = mode != 1;  // mode 1: foot 2 in flight; mode 2: foot 1 in flight
+    const double* u = Z + (int64_t)b * P.z_stride + 20 * k + 15;
+    double* d = D + 4 * t;
+    d[0] = on1 ? mu * u[1] - u[0] : 0.0;
+    d[1] = on1 ? mu * u[1] + u[0] : 0.0;
+    d[2] = on2 ? mu * u[3] - u[2] : 0.0;
+    d[3] = on2 ? mu * u[3] + u[2] : 0.0;
+    if (JV) {
+        double* j = JV + 8 * t;
+        j[0] = on1 ? -1.0 : 0.0, j[1] = on1 ? mu : 0.0, j[2] = on1 ? 1.0 : 0.0, j[3] = on1 ? mu : 0.0;
+        j[4] = on2 ? -1.0 : 0.0, j[5] = on2 ? mu : 0.0, j[6] = on2 ? 1.0 : 0.0, j[7] = on2 ? mu : 0.0;
+    }
+}
+
 template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
@@ -972,6 +996,13 @@ hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, dou
 hipError_t launch_kinematic_rows(const BatchParams& p, const double* Z, double* d, double* jac_vals, hipStream_t stream) {
     const int64_t n = (int64_t)p.B * p.N;
     hipLaunchKernelGGL(k_kinematic_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, Z, d, jac_vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_friction_rows(const BatchParams& p, const double* Z, double mu, double* d, double* jac_vals, hipStream_t stream) {
+    const int64_t n = (int64_t)p.B * (p.N - 1);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_friction_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, Z, mu, d, jac_vals);
     return hipGetLastError();
 }
 

@@ -458,6 +458,19 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_kinematic_bounds(self._h, C.byref(lo), C.byref(up)))
         return d.view(self.B, 2 * self.N), (jac.view(self.B, 2 * self.N, 4) if jac is not None else None), (lo.value, up.value)
 
+    def friction_cone(self, Z, mu: float, with_jacobian: bool = True):
+        """OPT-IN, nothing in the reference to compare with (it has no friction constraint): the friction pyramid
+        |F_x| <= mu F_y of the feet that stand on the ground at each dynamics knot, two linear rows per foot, bounds
+        0 <= d < inf.  Returns (d (B, N-1, 4), jac (B, N-1, 4, 2) or None); see qln_eval_friction_cone."""
+        t = _torch()
+        self._check(Z, self.dims.z_total, "Z")
+        n = self.B * (self.N - 1)
+        d = t.empty(4 * n, dtype=t.float64, device=self._dev())
+        jac = t.empty(8 * n, dtype=t.float64, device=self._dev()) if with_jacobian else None
+        _lib.check(_lib.lib().qln_eval_friction_cone(self._h, Z.data_ptr(), float(mu), d.data_ptr(),
+                                                     jac.data_ptr() if jac is not None else None))
+        return d.view(self.B, self.N - 1, 4), (jac.view(self.B, self.N - 1, 4, 2) if jac is not None else None)
+
     def constraint_violation(self, c, out=None):
         """Per-problem constraint violation as Ipopt reports it (src/main.ipynb:712) -> (B,) tensor."""
         out = self.new_f() if out is None else out
