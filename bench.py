@@ -462,6 +462,24 @@ def run_ranks(args):
                 "note": "qln_solve (augmented-Lagrangian iLQR, one wave per problem) from qln_initial_guess's Z0; violation = "
                         "qln_constraint_violation of the returned Z (Ipopt's definition)"}
             del b2, n2, Z2, c2, v2, Zs
+            # ... and every problem of the bench workload itself (65 536 of them at the default): the large-batch regime,
+            # two waves per SIMD (uniform workloads; the ragged one draws transition knots no landing is feasible for)
+            if not WORKLOADS[args.workload]["ragged"]:
+                Zs = nlp.initial_guess()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                Zs, sinfo = nlp.solve(Zs)
+                torch.cuda.synchronize()
+                ts = time.perf_counter() - ts
+                sviol = nlp.constraint_violation(nlp.eval_c(Zs)).cpu().numpy()
+                si = sinfo.cpu().numpy()
+                out["other"][f"solve_{args.workload}_B{batch.B}_N{batch.N}"] = {
+                    "solved_problems_per_s": float((sviol <= 1e-6 * 1.0001).sum()) / ts, "wall_ms": ts * 1e3,
+                    "problems": int(batch.B), "solved_to_1e-6": int((sviol <= 1e-6 * 1.0001).sum()),
+                    "ilqr_iterations_median": float(np.median(si[:, 1])), "ilqr_iterations_max": float(si[:, 1].max()),
+                    "violation_max": float(sviol.max()), "objective_median": float(np.median(si[:, 2])),
+                    "note": "the same on the bench workload's own problems (its drop states, the notebook's initial guess)"}
+                del Zs, sinfo
         if world == 1 and not args.no_cpu_baseline:
             one, allc = cpu_baseline(batch, nlp, Z)
             out["cpu_baseline"] = one
