@@ -36,7 +36,13 @@ namespace {
 
 constexpr int kCUs = 256;                  // MI355X
 constexpr size_t kLdsPerCU = 160 * 1024;
-constexpr int kAlphas = 16;    // step lengths tried per iteration: 2^0 .. 2^-15
+#ifndef QLN_ALPHAS
+#define QLN_ALPHAS 16
+#define QLN_ALPHA_STEP 1
+#endif
+constexpr int kAlphas = QLN_ALPHAS;        // step lengths tried per iteration: alpha_a = 2^(-a kAlphaStep), a = 0 .. kAlphas-1
+constexpr int kAlphaStep = QLN_ALPHA_STEP;
+constexpr int kPerTraj = kWave / kAlphas;  // lanes that share the merit evaluation of one trial trajectory
 constexpr int kIneq = 6;       // inequality rows per knot
 constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85 used)
 constexpr int kKn = 9;         // per-knot scalars kept in LDS
@@ -845,13 +851,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             double J_try = INFINITY;
             {
                 const int a = lane & (kAlphas - 1);
-                const double alpha = ldexp(1.0, -a);
+                const double alpha = ldexp(1.0, -a * kAlphaStep);
                 double* __restrict__ tz = traj + a;
                 double x[15], u[5], xn[15];
 #pragma unroll
                 for (int i = 0; i < 15; ++i) x[i] = L.X[i];
                 {
-                    const double g0 = Kg[lane], g1 = Kg[64 + a];
+                    const double g0 = Kg[lane], g1 = Kg[64 + (lane & 15)];
                     L.T[lane] = g0;
                     if (lane < 16) L.T[64 + lane] = g1;
                 }
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     const double* kc = (k & 1) ? L.Qxx : L.T;
                     double* kx = (k & 1) ? L.T : L.Qxx;
                     const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 1, N - 2);
-                    const double g0 = kp[lane], g1 = kp[64 + a];
+                    const double g0 = kp[lane], g1 = kp[64 + (lane & 15)];
                     if (lane < kAlphas) {
 #pragma unroll
                         for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * kc[16 * j + 15];
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 }
                 __threadfence();  // the trajectories written by lanes < 16 are read back by all
                 // merit: lane = (trajectory a, knots k = s, s + 4, ...), the four partial sums of a trajectory then added
-                const int s4 = lane >> 4;
+                const int s4 = lane / kAlphas;
                 double J = 0.0;
                 // (the loads of a knot are requested one pass ahead: a pass is then as long as its arithmetic)
                 double xr[15], ur[5], lr[kIneq];
@@ -900,7 +906,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int j = 0; j < kIneq; ++j) lo[j] = lamg[kIneq * kk + j];
                 };
                 fetch(s4, xr, ur, lr);
-                for (int k = s4; k < N; k += 4) {
+                for (int k = s4; k < N; k += kPerTraj) {
                     double uk[5], lk[kIneq];
 #pragma unroll
                     for (int i = 0; i < 15; ++i) x[i] = xr[i];
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int j = 0; j < 5; ++j) uk[j] = (k < N - 1) ? ur[j] : 0.0;
 #pragma unroll
                     for (int j = 0; j < kIneq; ++j) lk[j] = lr[j];
-                    fetch(k + 4, xr, ur, lr);
+                    fetch(k + kPerTraj, xr, ur, lr);
                     const double w = (k < N - 1) ? (exact_h ? uk[4] : L.kn[kKn * k + KN_W]) : 1.0;
                     StageIn I = stage_in(k, rho, w);
                     I.lam5 = lk;
@@ -916,8 +922,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     stage_eval(I, x, uk, o);
                     J += o.val;
                 }
-                J += __shfl_xor(J, 16, kWave);
-                J += __shfl_xor(J, 32, kWave);
+#pragma unroll
+                for (int off = kAlphas; off < kWave; off <<= 1) J += __shfl_xor(J, off, kWave);
                 J_try = J;
             }
             QLN_TICK(tk_roll);
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 continue;
             }
             const double J_new = J_best;
-            last_alpha = ldexp(1.0, -a_star);
+            last_alpha = ldexp(1.0, -a_star * kAlphaStep);
             // accept: lane a_star's roll-out becomes the current trajectory (x_1 = x0 stays)
             __threadfence();
             wave_lds_sync();
