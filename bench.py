@@ -319,6 +319,39 @@ def run_single_process(args):
     return out
 
 
+class _GlooComm:
+    """Stand-in with multi.Comm's interface over the gloo group (host memory): only used when RCCL could not be brought
+    up on every rank, so that the job still reports (the JSON line then names the fallback)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def gather(self, t, root: int = 0, stream=None):
+        import torch
+        from quadruped_landing_amd import distributed as D
+
+        parts = D.gather_to_root(t.detach().cpu().contiguous(), dst=root)
+        if self.rank != root:
+            return None, None
+        return torch.cat(parts).to(t.device), [int(p.numel()) for p in parts]
+
+    def max(self, value: float) -> float:
+        import torch
+        import torch.distributed as dist
+
+        v = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def barrier(self):
+        import torch.distributed as dist
+
+        dist.barrier()
+
+    def close(self):
+        pass
+
+
 def run_ranks(args):
     """One process per GPU.  Under a launcher (the driver's `python -m torch.distributed.run --nproc-per-node N ...`)
     every rank builds its shard locally and evaluates it with its own handle; there is no data-path collective.  RCCL
@@ -335,13 +368,35 @@ def run_ranks(args):
     force_dist = os.environ.get("QLN_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
     multi_rank = world > 1 or force_dist
     comm = None
+    rccl_error = None
     if multi_rank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        uid = [multi.Comm.unique_id() if rank == 0 else None]
+        # RCCL through the C ABI.  Should a rank fail to create its communicator, EVERY rank falls back to carrying the
+        # end-of-job exchange over the gloo group (host memory): the line is still printed, and says so.
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [multi.Comm.unique_id()]
+            except Exception as e:  # noqa: BLE001 -- reported below
+                rccl_error = repr(e)
         dist.broadcast_object_list(uid, src=0)
-        comm = multi.Comm(uid[0], rank, world, local_rank)
+        if uid[0] is not None:
+            try:
+                if os.environ.get("QLN_BENCH_SIMULATE_RCCL_FAILURE") == "1":  # exercises the fallback below (tests only)
+                    raise RuntimeError("simulated")
+                comm = multi.Comm(uid[0], rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001
+                rccl_error = repr(e)
+        failed = torch.tensor([0 if comm is not None else 1])
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            if comm is not None:
+                comm.close()
+            rccl_error = rccl_error or "another rank could not create its RCCL communicator"
+            print(f"bench.py rank {rank}: RCCL unavailable ({rccl_error}); the gather goes over gloo", file=sys.stderr)
+            comm = _GlooComm(rank, world)
 
     # weak scaling: every rank owns a full-size shard of the global batch (seeded by its rank)
     batch, nlp, Z, c, vals = build(args.workload, seed=rank, device=local_rank, placement_trials=args.placement_trials,
@@ -396,7 +451,8 @@ def run_ranks(args):
     out = None
     if rank == 0:
         out = base_record(args, batch.B * batch.N * world * K / elapsed, world, elapsed, batch.B, batch.N, nlp.z_stride,
-                          {"driver": "one process per GPU" + (", RCCL through qln_comm_* (include/qln_multi.h)" if comm is not None else ""),
+                          {"driver": "one process per GPU" + ("" if comm is None else ", RCCL through qln_comm_* (include/qln_multi.h)" if rccl_error is None
+                                                          else f", RCCL UNAVAILABLE ({rccl_error}): end-of-job gather over gloo (host memory)"),
                            "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms, "workload_data": data_how})
         out["roofline"] = roofline_record(args, batch, ms_each)
         if comm is not None:

@@ -132,3 +132,38 @@ def test_two_rank_hip_shards_gathered_match_the_global_oracle(ragged):
     its shard_range of the batch (both on the one visible device), gathered to rank 0 and compared with the oracle
     evaluated on the global index."""
     _run_two_ranks(ragged, use_gpu=True)
+
+
+def _gloo_comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        comm = bench._GlooComm(rank, world)
+        t = torch.arange(5 + 3 * rank, dtype=torch.float64) + 100 * rank  # ragged: 5 and 8 entries
+        out, counts = comm.gather(t)
+        m = comm.max(float(10 - rank))
+        comm.barrier()
+        if rank == 0:
+            want = torch.cat([torch.arange(5, dtype=torch.float64), torch.arange(8, dtype=torch.float64) + 100])
+            q.put(bool(torch.equal(out, want) and counts == [5, 8] and m == 10.0))
+        else:
+            assert out is None and m == 10.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_fallback_comm_over_gloo():
+    """bench.py's stand-in for multi.Comm when RCCL cannot be brought up on every rank: ragged gather, max, barrier."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
