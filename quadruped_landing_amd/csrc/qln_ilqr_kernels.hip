@@ -280,9 +280,9 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
     QLN_TAKE(A, 300)  // A (15x15, stride 15) then B (15x5)
     t.B = t.A ? t.A + 225 : nullptr;
     QLN_TAKE(T, 240)  // [T | pv]
+    QLN_TAKE(Qxx, 240)  // [Qxx | Qx]     (P .. Qxx: 1020 contiguous doubles, the roll-outs' (x, u) slots)
     QLN_TAKE(S, 80)
     t.K = t.S;  // gains of the knot being swept, 5 rows of 16 (S is dead once Quu is formed); all knots: global scratch
-    QLN_TAKE(Qxx, 240)  // [Qxx | Qx]
     QLN_TAKE(Qux, 80)   // [Qux | Qu]
     QLN_TAKE(Quu, 26)
     QLN_TAKE(g, 20)
@@ -844,29 +844,43 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             __threadfence();  // the gains written during the sweep are read back by the roll-out lanes
             // ---- forward: one closed-loop roll-out per step length, lane a < 16 tries alpha = 2^-a and keeps its
             //      trajectory in the scratch, so that the accepted one need not be rolled out again.  Only the
-            //      state recursion is serial: the gains of the next knot are fetched by all 64 lanes (coalesced) while
-            //      the sixteen roll-out lanes take their step, and handed over through LDS (T and Qxx of the sweep are
-            //      free now: 80 doubles each); the merit of the sixteen trajectories is evaluated afterwards, four
-            //      lanes per trajectory.
+            //      state recursion is serial.  The other 48 lanes work for the sixteen: all 64 fetch the next knot's
+            //      gains (coalesced) while the sixteen take their step, handed over through LDS (S and Qux of the sweep:
+            //      80 doubles each); and the merit of the trial trajectories is evaluated three knots at a time by the
+            //      three idle lane groups, from (x_k, u_k) the roll-out lanes leave in LDS (the sweep's P, A, T, Qxx are
+            //      free now) -- nothing of a trial trajectory is read back from memory but the accepted one.
             double J_try = INFINITY;
             {
-                const int a = lane & (kAlphas - 1);
+                constexpr int kGroups = kPerTraj - 1;  // helper lane groups: lanes 16-31, 32-47, 48-63
+                static_assert(kGroups >= 1 && kGroups * kAlphas * 20 <= 1020, "the (x, u) slots live in the sweep's P, A, T, Qxx");
+                double* const slots = L.P;  // [kGroups][kAlphas][20]
+                const int a = lane & (kAlphas - 1), grp = lane / kAlphas - 1;  // grp = -1: a roll-out lane
                 const double alpha = ldexp(1.0, -a * kAlphaStep);
                 double* __restrict__ tz = traj + a;
                 double x[15], u[5], xn[15];
+                double J = 0.0;
 #pragma unroll
                 for (int i = 0; i < 15; ++i) x[i] = L.X[i];
                 {
                     const double g0 = Kg[lane], g1 = Kg[64 + (lane & 15)];
-                    L.T[lane] = g0;
-                    if (lane < 16) L.T[64 + lane] = g1;
+                    L.S[lane] = g0;
+                    if (lane < 16) L.S[64 + lane] = g1;
                 }
+                // a helper lane's multipliers are requested a batch ahead (global scratch)
+                double lr[kIneq];
+                auto fetch_lam = [=](int kk, double (&lo)[kIneq]) {
+                    const int kq = min(max(kk, 0), N - 1);
+#pragma unroll
+                    for (int j = 0; j < kIneq; ++j) lo[j] = lamg[kIneq * kq + j];
+                };
+                fetch_lam(grp, lr);
                 wave_lds_sync();
                 for (int k = 0; k < N - 1; ++k) {
-                    const double* kc = (k & 1) ? L.Qxx : L.T;
-                    double* kx = (k & 1) ? L.T : L.Qxx;
+                    const double* kc = (k & 1) ? L.Qux : L.S;
+                    double* kx = (k & 1) ? L.S : L.Qux;
                     const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 1, N - 2);
                     const double g0 = kp[lane], g1 = kp[64 + (lane & 15)];
+                    const int slot = k % kGroups;
                     if (lane < kAlphas) {
 #pragma unroll
                         for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * kc[16 * j + 15];
@@ -877,8 +891,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             for (int j = 0; j < 5; ++j) u[j] = fma(kc[16 * j + i], dx, u[j]);
                         }
                         u[4] = fmin(fmax(u[4], h_lo), h_hi);
+                        double* sl = slots + (slot * kAlphas + a) * 20;
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) tz[kAlphas * (20 * k + 15 + j)] = u[j];
+                        for (int i = 0; i < 15; ++i) sl[i] = x[i];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            sl[15 + j] = u[j];
+                            tz[kAlphas * (20 * k + 15 + j)] = u[j];
+                        }
                         step_fast(FS, k, kt, im, x, u, xn);
 #pragma unroll
                         for (int i = 0; i < 15; ++i) {
@@ -889,37 +909,30 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     kx[lane] = g0;
                     if (lane < 16) kx[64 + lane] = g1;
                     wave_lds_sync();
+                    if (slot == kGroups - 1 || k == N - 2) {  // a batch of knots kb .. k is complete (wave-uniform)
+                        const int kb = k - slot, kk = kb + grp;
+                        if (grp >= 0 && kk <= k) {
+                            const double* sl = slots + (grp * kAlphas + a) * 20;
+                            double xs[15], us[5];
+#pragma unroll
+                            for (int i = 0; i < 15; ++i) xs[i] = sl[i];
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) us[j] = sl[15 + j];
+                            const double w = exact_h ? us[4] : L.kn[kKn * kk + KN_W];
+                            StageIn I = stage_in(kk, rho, w);
+                            I.lam5 = lr;
+                            StageOut o;
+                            stage_eval(I, xs, us, o);
+                            J += o.val;
+                        }
+                        fetch_lam(kb + kGroups + grp, lr);
+                    }
                 }
-                __threadfence();  // the trajectories written by lanes < 16 are read back by all
-                // merit: lane = (trajectory a, knots k = s, s + 4, ...), the four partial sums of a trajectory then added
-                const int s4 = lane / kAlphas;
-                double J = 0.0;
-                // (the loads of a knot are requested one pass ahead: a pass is then as long as its arithmetic)
-                double xr[15], ur[5], lr[kIneq];
-                auto fetch = [=](int k, double (&xo)[15], double (&uo)[5], double (&lo)[kIneq]) {
-                    const int kk = min(k, N - 1);
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) xo[i] = (kk == 0) ? L.X[i] : tz[kAlphas * (20 * kk + i)];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) uo[j] = tz[kAlphas * (20 * min(kk, N - 2) + 15 + j)];
-#pragma unroll
-                    for (int j = 0; j < kIneq; ++j) lo[j] = lamg[kIneq * kk + j];
-                };
-                fetch(s4, xr, ur, lr);
-                for (int k = s4; k < N; k += kPerTraj) {
-                    double uk[5], lk[kIneq];
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) x[i] = xr[i];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) uk[j] = (k < N - 1) ? ur[j] : 0.0;
-#pragma unroll
-                    for (int j = 0; j < kIneq; ++j) lk[j] = lr[j];
-                    fetch(k + kPerTraj, xr, ur, lr);
-                    const double w = (k < N - 1) ? (exact_h ? uk[4] : L.kn[kKn * k + KN_W]) : 1.0;
-                    StageIn I = stage_in(k, rho, w);
-                    I.lam5 = lk;
+                if (lane < kAlphas) {  // the terminal knot: the roll-out lanes hold x_N
+                    double u0[5] = {0, 0, 0, 0, 0};
+                    StageIn I = stage_in(N - 1, rho, 1.0);
                     StageOut o;
-                    stage_eval(I, x, uk, o);
+                    stage_eval(I, x, u0, o);
                     J += o.val;
                 }
 #pragma unroll
