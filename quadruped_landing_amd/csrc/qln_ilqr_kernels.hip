@@ -46,6 +46,7 @@ constexpr int kPerTraj = kWave / kAlphas;  // lanes that share the merit evaluat
 constexpr int kIneq = 6;       // inequality rows per knot
 constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85 used)
 constexpr int kKn = 9;         // per-knot scalars kept in LDS
+constexpr int kLd = 17;        // leading dimension of the sweep's LDS matrices: 16 columns + 1 (a stride of 16 doubles puts a column in two LDS banks)
 constexpr int kKg = 80;        // doubles per knot of the feedback law in the scratch: 5 rows of [15 gains, feed-forward]
 
 // per-knot scalars (lane = knot phase -> backward sweep)
@@ -276,14 +277,14 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
     t.field = base ? base + off : nullptr; \
     off += (size_t)(((n) + 1) & ~1);
     // the sweep's matrices first (compile-time offsets), row stride 16 -- see the sweep
-    QLN_TAKE(P, 240)
+    QLN_TAKE(P, 15 * kLd)
     QLN_TAKE(A, 300)  // A (15x15, stride 15) then B (15x5)
     t.B = t.A ? t.A + 225 : nullptr;
-    QLN_TAKE(T, 240)  // [T | pv]
-    QLN_TAKE(Qxx, 240)  // [Qxx | Qx]     (P .. Qxx: 1020 contiguous doubles, the roll-outs' (x, u) slots)
-    QLN_TAKE(S, 80)
+    QLN_TAKE(T, 15 * kLd)  // [T | pv]
+    QLN_TAKE(Qxx, 15 * kLd)  // [Qxx | Qx]     (P .. Qxx: contiguous, the roll-outs' (x, u) slots)
+    QLN_TAKE(S, 5 * kLd)
     t.K = t.S;  // gains of the knot being swept, 5 rows of 16 (S is dead once Quu is formed); all knots: global scratch
-    QLN_TAKE(Qux, 80)   // [Qux | Qu]
+    QLN_TAKE(Qux, 5 * kLd)   // [Qux | Qu]
     QLN_TAKE(Quu, 26)
     QLN_TAKE(g, 20)
     QLN_TAKE(Hd, 20)
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 const int k = N - 1;
                 const double* kn = L.kn + kKn * k;
                 const double* rec = costg + 41 * k;
-                for (int e = lane; e < 240; e += kWave) L.P[e] = 0.0;
+                for (int e = lane; e < 15 * kLd; e += kWave) L.P[e] = 0.0;
                 wave_lds_sync();
                 if (lane < 15) {
                     const int i = lane;
@@ -534,13 +535,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         gi += -kn[KN_T0 + 5];
                         hi += rho * act(kn[KN_T0 + 5]);
                     }
-                    L.T[16 * i + 15] = gi;
-                    L.P[17 * i] = hi;
+                    L.T[kLd * i + 15] = gi;
+                    L.P[(kLd + 1) * i] = hi;
                 }
                 if (lane == 0) {
                     const double off = -rho * (act(kn[KN_T0 + 0]) - act(kn[KN_T0 + 1])) * kn[KN_CQ];
-                    L.P[16 * 1 + 2] = off;
-                    L.P[16 * 2 + 1] = off;
+                    L.P[kLd * 1 + 2] = off;
+                    L.P[kLd * 2 + 1] = off;
                 }
                 wave_lds_sync();
             }
@@ -617,14 +618,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
                         if (r < 15 && cv) {
-                            const double* pr = L.P + 16 * r;
-                            L.T[16 * r + c] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[c] * a0)));
+                            const double* pr = L.P + kLd * r;
+                            L.T[kLd * r + c] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[c] * a0)));
                         }
                     }
                 }
                 if (ln < 60) {
                     const int r = ln >> 2, j = ln & 3;
-                    const double* pr = L.P + 16 * r;
+                    const double* pr = L.P + kLd * r;
                     int rows[6];
                     b_rows(j, rows);
                     double acc = 0.0, ah = 0.0;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 // ---- [Qxx | Qx] = [Hxx | gx] + A'[T | pv] ----
                 {
                     const int c = ln & 15;
-                    const double t2 = L.T[32 + c], t9 = L.T[144 + c];
+                    const double t2 = L.T[2 * kLd + c], t9 = L.T[9 * kLd + c];
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
@@ -654,11 +655,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
                             const double a0 = L.A[16 * r], a2 = (r == 2) ? 0.0 : L.A[30 + r], a9 = (r == 9) ? 0.0 : L.A[135 + r];
                             const double ac = (rp >= 0) ? L.A[15 * rp + r] : 0.0;
-                            acc = fma(a0, L.T[16 * r + c], acc);
+                            acc = fma(a0, L.T[kLd * r + c], acc);
                             acc = fma(a2, t2, acc);
                             acc = fma(a9, t9, acc);
-                            acc = fma(ac, L.T[16 * max(rp, 0) + c], acc);
-                            L.Qxx[16 * r + c] = acc;
+                            acc = fma(ac, L.T[kLd * max(rp, 0) + c], acc);
+                            L.Qxx[kLd * r + c] = acc;
                         }
                     }
                 }
@@ -669,8 +670,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     b_rows(j, rows);
                     double acc = (c == 15) ? L.g[15 + j] : 0.0;
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[16 * rows[q] + c], acc);
-                    L.Qux[16 * j + c] = acc;
+                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[kLd * rows[q] + c], acc);
+                    L.Qux[kLd * j + c] = acc;
                 }
                 {
                     const int c = ln >> 2, p = ln & 3;
@@ -679,10 +680,10 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int t = 0; t < 4; ++t) {
                         const int i = p + 4 * t, ic = min(i, 14);
                         const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
-                        ah = fma(bv, L.T[16 * ic + c], ah);
+                        ah = fma(bv, L.T[kLd * ic + c], ah);
                     }
                     ah = quad_sum(ah);
-                    if (p == 0) L.Qux[64 + c] = ah + ((c == 15) ? L.g[19] : 0.0);
+                    if (p == 0) L.Qux[4 * kLd + c] = ah + ((c == 15) ? L.g[19] : 0.0);
                 }
                 // ---- Quu = Huu + B'S + mu I: the force rows (and, by symmetry, the h row), then (h, h) in a quad ----
                 if (ln < 32) {
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 double qu[5], dff[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    qu[i] = L.Qux[16 * i + 15];
+                    qu[i] = L.Qux[kLd * i + 15];
                     dff[i] = -qu[i];
                 }
                 ldl_solve(dff, 5);
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 double kc[5] = {0, 0, 0, 0, 0};
                 if (ln < 15) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[16 * i + ln];
+                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[kLd * i + ln];
                     if (clamped) {
                         kc[4] = 0.0;
                         ldl_solve(kc, 4);
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         ldl_solve(kc, 5);
                     }
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) L.K[16 * i + ln] = kc[i];
+                    for (int i = 0; i < 5; ++i) L.K[kLd * i + ln] = kc[i];
                 }
                 if (ln < 16) {  // row i of the knot's record: 15 gains, then the feed-forward d_i
 #pragma unroll
@@ -806,28 +807,28 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     double qc[5], kcol[5];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        qc[i] = L.Qux[16 * i + cc];
-                        kcol[i] = L.K[16 * i + cc];
+                        qc[i] = L.Qux[kLd * i + cc];
+                        kcol[i] = L.K[kLd * i + cc];
                     }
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
                         if (r < 15 && cv) {
-                            double acc = L.Qxx[16 * r + c], act_ = L.Qxx[16 * c + r];
+                            double acc = L.Qxx[kLd * r + c], act_ = L.Qxx[kLd * c + r];
 #pragma unroll
                             for (int i = 0; i < 5; ++i) {
-                                acc = fma(L.Qux[16 * i + r], kcol[i], acc);
-                                act_ = fma(qc[i], L.K[16 * i + r], act_);
+                                acc = fma(L.Qux[kLd * i + r], kcol[i], acc);
+                                act_ = fma(qc[i], L.K[kLd * i + r], act_);
                             }
-                            L.P[16 * r + c] = 0.5 * (acc + act_);
+                            L.P[kLd * r + c] = 0.5 * (acc + act_);
                         }
                     }
                 }
                 if (ln < 15) {
-                    double acc = L.Qxx[16 * ln + 15];
+                    double acc = L.Qxx[kLd * ln + 15];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = fma(L.Qux[16 * i + ln], dff[i], acc);
-                    L.T[16 * ln + 15] = acc;
+                    for (int i = 0; i < 5; ++i) acc = fma(L.Qux[kLd * i + ln], dff[i], acc);
+                    L.T[kLd * ln + 15] = acc;
                 }
                 wave_lds_sync();
             }
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             double J_try = INFINITY;
             {
                 constexpr int kGroups = kPerTraj - 1;  // helper lane groups: lanes 16-31, 32-47, 48-63
-                static_assert(kGroups >= 1 && kGroups * kAlphas * 20 <= 1020, "the (x, u) slots live in the sweep's P, A, T, Qxx");
+                static_assert(kGroups >= 1 && kGroups * kAlphas * 20 <= 3 * ((15 * kLd + 1) & ~1) + 300, "the (x, u) slots live in the sweep's P, A, T, Qxx");
                 double* const slots = L.P;  // [kGroups][kAlphas][20]
                 const int a = lane & (kAlphas - 1), grp = lane / kAlphas - 1;  // grp = -1: a roll-out lane
                 const double alpha = ldexp(1.0, -a * kAlphaStep);
