@@ -867,6 +867,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     L.S[lane] = g0;
                     if (lane < 16) L.S[64 + lane] = g1;
                 }
+                // the gains of knot k+1 are requested during knot k-1 and parked in LDS at the end of knot k: a whole knot
+                // of arithmetic between a load and its first use
+                double g0, g1;
+                {
+                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(1, N - 2);
+                    g0 = kp[lane], g1 = kp[64 + (lane & 15)];
+                }
                 // a helper lane's multipliers are requested a batch ahead (global scratch)
                 double lr[kIneq];
                 auto fetch_lam = [=](int kk, double (&lo)[kIneq]) {
@@ -879,8 +886,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 for (int k = 0; k < N - 1; ++k) {
                     const double* kc = (k & 1) ? L.Qux : L.S;
                     double* kx = (k & 1) ? L.S : L.Qux;
-                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 1, N - 2);
-                    const double g0 = kp[lane], g1 = kp[64 + (lane & 15)];
+                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 2, N - 2);
+                    const double h0 = kp[lane], h1 = kp[64 + (lane & 15)];
                     const int slot = k % kGroups;
                     if (lane < kAlphas) {
 #pragma unroll
@@ -909,6 +916,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     }
                     kx[lane] = g0;
                     if (lane < 16) kx[64 + lane] = g1;
+                    g0 = h0, g1 = h1;
                     wave_lds_sync();
                     if (slot == kGroups - 1 || k == N - 2) {  // a batch of knots kb .. k is complete (wave-uniform)
                         const int kb = k - slot, kk = kb + grp;
