@@ -22,7 +22,7 @@
 // once per sweep by lane = knot and parked in a global scratch.  Per problem that scratch holds the step entries
 // (88 N doubles), the feedback law of every knot (80 N), the sixteen trial trajectories (320 N) and the inequality
 // multipliers (6 N); the wave's LDS holds the current trajectory, 9 scalars per knot and the sweep's matrices
-// (29 N + 1.3 k doubles: 19.8 KB at N = 40, eight waves per CU).
+// (29 N + 1.4 k doubles: 20.3 KB at N = 40, eight waves per CU).
 //
 // The reference holds nothing to compare the iterates with (it hands its callbacks to Ipopt 3.13 + MUMPS); the result
 // is checked by the evaluator itself: constraint violation and objective of the returned Z (tests/test_gpu_solve.py).
