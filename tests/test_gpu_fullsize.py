@@ -259,3 +259,41 @@ def test_gpu_jacobian_is_the_derivative_of_the_gpu_constraints(B, N, ragged):
     worst_b = max(worst_b, float(((jv[ridx] - fd[ridx]).abs() * live).max()))
     print(f"B={B} N={N} ragged={ragged}: |J v - central difference| / (1 + |J||v|): step blocks {worst_a:.2e}; other rows (absolute) {worst_b:.2e}")
     assert worst_a <= 1e-7 and worst_b <= 1e-7
+
+
+def test_translation_and_clock_shift_invariance_at_full_size():
+    """Two more properties of the model (src/planar_quadruped.jl:36-185) that need no reference data: nothing but the
+    differences x_foot - xb enters the dynamics, and the clock state enters only its own row.  Shifting every horizontal
+    position of BASELINE.json configs[2]'s batch by 0.25 m, and every clock by 1 s, must leave the dynamics residuals, the
+    contact / final-control / clearance rows and every Jacobian value unchanged (to rounding: the shifted sums round
+    differently), and move only the initial / terminal rows of the shifted entries -- by exactly the shift."""
+    import torch
+
+    B, N = 65536, 40
+    batch, nlp, Z = _setup(B, N, False, seed=9)
+    c0, v0 = nlp.eval_c_and_jac(Z)
+    c0, v0 = c0.clone(), v0.clone()
+    dx, dt = 0.25, 1.0
+    shift = torch.zeros(20, dtype=torch.float64, device=Z.device)
+    shift[[0, 3, 5]] = dx   # xb, x1, x2
+    shift[14] = dt          # the clock
+    Zs = Z.clone().view(B, -1)
+    n_nlp = 20 * N - 5
+    Zs[:, :n_nlp] += shift.repeat(N)[:n_nlp]
+    c1, v1 = nlp.eval_c_and_jac(Zs.view(-1))
+    torch.cuda.synchronize()
+    sc = int(nlp.c_off[1] - nlp.c_off[0])
+    m = nlp.problem_dims(0)[0]
+    a = c0.as_strided((B, m), (sc, 1))
+    b = c1.as_strided((B, m), (sc, 1))
+    d = (b - a)
+    want = torch.zeros(m, dtype=torch.float64, device=Z.device)
+    want[[0, 3, 5]] = dx
+    want[14] = dt
+    want[[15 + 0, 15 + 3, 15 + 5]] = dx   # terminal rows x_N[1:14] - xf (the clock is not among them)
+    err = (d - want).abs().max().item()
+    scale = a.abs().max().item()
+    jerr = ((v1 - v0).abs().max() / v0.abs().max()).item()
+    print(f"rows: max |c(shifted) - c - expected shift| = {err:.2e} (largest |c| {scale:.1f}); Jacobian values: max relative change {jerr:.2e}")
+    assert err <= 1e-12 * max(1.0, scale)
+    assert jerr <= 1e-13
