@@ -195,10 +195,10 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~650).  Stream-ordered. */
 typedef struct qln_solve_options {
     int32_t max_outer;        /* multiplier updates                                   default 80   */
-    int32_t max_inner;        /* iLQR iterations per multiplier update (inexact inner solves pay)   default 8 */
+    int32_t max_inner;        /* iLQR iterations per multiplier update (inexact inner solves pay)   default 6 */
     double tol_violation;     /* stop when the violation is <= this                   default 1e-6 (solve()'s c_tol) */
     double inner_tol;         /* inner loop ends when the cost decrease is below inner_tol (1 + |J|)   default 1e-7 */
-    double rho0, rho_factor, rho_max;  /* penalty schedule                            default 10, 5, 1e8 */
+    double rho0, rho_factor, rho_max;  /* penalty schedule                            default 3, 5, 1e8 */
     double h_min, h_max;      /* bounds on the step length (src/moi.jl:58-61)         default 0.001, 0.02 */
     double theta_min, theta_max;       /* bounds on the body angle (src/moi.jl:54-56) default -pi/2, pi/2 */
     int32_t q6_bounds;        /* the lower bounds of quirk Q6 (yb_{k+1}, x1_{k+1} >= 0, src/moi.jl:64-65)  default 1 */

@@ -610,10 +610,10 @@ int qln_solve_default_options(qln_solve_options* o) {
     // random N = 40 problems (profiles/r02_solve_sweep_options.txt): 60 inner iterations and rho x10 from 1 take a median
     // of 214 iterations; 8 inner iterations and rho x5 from 10 solve the same 16 384 with a median of 75 (max 144).
     o->max_outer = 80;
-    o->max_inner = 8;
+    o->max_inner = 6;
     o->tol_violation = 1e-6;
     o->inner_tol = 1e-7;
-    o->rho0 = 10.0;
+    o->rho0 = 3.0;
     o->rho_factor = 5.0;
     o->rho_max = 1e8;
     o->h_min = 0.001;   // src/moi.jl:59-60
