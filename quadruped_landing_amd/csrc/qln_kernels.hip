@@ -730,6 +730,54 @@ __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const
 // with U = Uref of reference_trajectory (src/ref_traj.jl:19-34): the step BEFORE the hot path, built where the
 // evaluator will read it.  One thread per entry of Z; same operation order as the notebook, so the result is
 // bit-identical to the host generator (quadruped_landing_amd/problem_gen.py).
+// grad_f! for a batch that shares one cost table (cost_batch == 1): persistent four-wave workgroups with the table in LDS,
+// one problem per wave at a time, the next problem's row of Z in flight while this one's gradient is formed.  Only the
+// step lengths h_k go through LDS, so that every entry finds its knot's (src/costs.jl:26-31; no d(h l)/dh: quirk Q2).
+__global__ __launch_bounds__(4 * kWave) void k_objective_gradient_shared(BatchParams P, const double* __restrict__ Z,
+                                                                         double* __restrict__ G) {
+    extern __shared__ double s_dyn[];
+    const int N = P.N;
+    const int n_nlp = 20 * N - 5;
+    double* s_cost = s_dyn;  // [N][41]
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * kWave;  // the wave's h_k, k < N - 1 <= 63
+    for (int i = threadIdx.x; i < 41 * N; i += blockDim.x) s_cost[i] = P.cost[i];
+    __syncthreads();
+    constexpr int kIters = 20;  // 20 * 64 >= 20 N for N <= 64
+    const int stride = gridDim.x * 4;
+    int b = blockIdx.x * 4 + wave;
+    double zr[kIters];
+    if (b < P.B) {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)b * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+    }
+    for (; b < P.B; b += stride) {
+        wave_lds_sync();  // the previous problem's readers are done
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {  // only the step lengths h_k = u_k[5] are needed by other lanes
+            const int e = it * kWave + lane, k = e / 20;
+            if (e < n_nlp && e - 20 * k == 19) s_z[k] = zr[it];
+        }
+        wave_lds_sync();
+        double* __restrict__ Gb = G + (int64_t)b * P.z_stride;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int e = it * kWave + lane;
+            if (e < n_nlp) {
+                const int k = e / 20, j = e - 20 * k;
+                const double lin = s_cost[41 * k + j] * zr[it] + s_cost[41 * k + 20 + j];
+                const double gv = (k < N - 1) ? s_z[k] * lin : lin;
+                __builtin_nontemporal_store(gv, &Gb[e]);
+            }
+        }
+        const int bn = b + stride;  // the next problem's row
+        if (bn < P.B) {
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)bn * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __restrict__ Z) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
@@ -1046,6 +1094,15 @@ hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t str
 }
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
+    if (p.cost_batch == 1 && p.N <= kWave && p.B >= 4096) {
+        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + 4 * kWave) * sizeof(double);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+        const int grid = std::min(256 * per_cu, (p.B + 3) / 4);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_gradient_shared), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_objective_gradient_shared, dim3(grid), dim3(4 * kWave), lds, stream, p, Z, grad);
+        return hipGetLastError();
+    }
     const int64_t total = (int64_t)p.B * (20 * p.N - 5);
     const int ntiles = (int)((total + kGradU * 256 - 1) / (kGradU * 256));
     hipLaunchKernelGGL(k_objective_gradient, dim3(xcd_grid(ntiles)), dim3(256), 0, stream, p, Z, grad, total, ntiles);
