@@ -192,7 +192,10 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * augmented cost, last accepted step length, sum of h, LM mu at exit, five phase timers, 1 if the rescue phase ran}.
  * There is no reference oracle for the iterates (the reference hands its callbacks to Ipopt); the result is judged by
  * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
- * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~650).  Stream-ordered. */
+ * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~650).  Stream-ordered.
+ * The first call on a handle allocates the solver's device scratch, 494 N doubles per problem (158 KB at N = 40: step
+ * entries, feedback laws, the sixteen trial trajectories, multipliers), kept until qln_destroy -- a 10-GB hipMalloc at
+ * B = 65 536 that took between a few ms and 2 s on this pool's boxes: make one throw-away call before timing. */
 typedef struct qln_solve_options {
     int32_t max_outer;        /* multiplier updates                                   default 80   */
     int32_t max_inner;        /* iLQR iterations per multiplier update (inexact inner solves pay)   default 6 */
