@@ -30,6 +30,9 @@
 #include <cstdlib>
 #endif
 
+#ifndef QLN_OBJ_WAVES
+#define QLN_OBJ_WAVES 8  // waves per workgroup of k_objective_shared
+#endif
 namespace qln {
 
 #ifdef QLN_DIAG
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(kWave) void k_jacobian_constants(BatchParams P, dou
 // the first wait) into LDS -- the only LDS the kernel uses, 10 KB, so that a CU holds 14 waves -- and lane = knot
 // forms its term straight from there.
 __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
-    constexpr int kSlice = kWave * 20;
+    constexpr int kSlice = kWave * 21;  // a knot's 20 entries 21 doubles apart (LDS banks: lane = knot reads them)
     __shared__ double s_z[kSlice];
     __shared__ double s_term[kWave];
     const int lane = threadIdx.x;
@@ -624,11 +627,11 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
         for (int it = 0; it < 20; ++it) zr[it] = Zb[20 * k0 + min(it * kWave + lane, ne - 1)];  // clamped, not predicated
         wave_lds_sync();  // the previous pass's readers are done
 #pragma unroll
-        for (int it = 0; it < 20; ++it) s_z[it * kWave + lane] = zr[it];
+        for (int it = 0; it < 20; ++it) s_z[it * kWave + lane + (it * kWave + lane) / 20] = zr[it];
         wave_lds_sync();
         const int kl = min(lane, nk - 1);
         const int k = k0 + kl;
-        const double term = objective_term(s_z + 20 * kl, cost + (int64_t)k * 41, k < N - 1);
+        const double term = objective_term(s_z + 21 * kl, cost + (int64_t)k * 41, k < N - 1);
         J = add_terms_in_order(J, (lane < nk) ? term : 0.0, s_term, lane);
     }
     if (lane == 0) F[b] = J;
@@ -639,21 +642,23 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
 // at a time -- lane = knot reads its record from LDS (stride 41 doubles: odd, no bank conflicts) instead of issuing 41
 // scattered 8-byte requests per lane to the texture path, which is what bounds k_objective on this workload -- and the next
 // problem's slice of Z is in flight while the current one is summed.
-__global__ __launch_bounds__(4 * kWave) void k_objective_shared(BatchParams P, const double* __restrict__ Z,
+template <int W>
+__global__ __launch_bounds__(W * kWave) void k_objective_shared(BatchParams P, const double* __restrict__ Z,
                                                                 double* __restrict__ F) {
     extern __shared__ double s_dyn[];
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
     double* s_cost = s_dyn;                                   // [N][41]
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int per_wave = 20 * N + kWave;
-    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * per_wave;  // [20 N]
-    double* s_term = s_z + 20 * N;                               // [64]
+    // a knot's 20 entries sit 21 doubles apart: lane = knot reads with a stride of 20 doubles would hit 8 of the 64 banks
+    const int per_wave = 21 * N + kWave;
+    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * per_wave;  // [N][21]
+    double* s_term = s_z + 21 * N;                               // [64]
     for (int i = threadIdx.x; i < 41 * N; i += blockDim.x) s_cost[i] = P.cost[i];
     __syncthreads();
     constexpr int kIters = 20;
-    const int stride = gridDim.x * 4;
-    int b = blockIdx.x * 4 + wave;
+    const int stride = gridDim.x * W;
+    int b = blockIdx.x * W + wave;
     double zr[kIters];
     if (b < P.B) {
 #pragma unroll
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(4 * kWave) void k_objective_shared(BatchParams P, c
         wave_lds_sync();  // the previous problem's readers are done
 #pragma unroll
         for (int it = 0; it < kIters; ++it)
-            if (it * kWave + lane < 20 * N) s_z[it * kWave + lane] = zr[it];
+            if (it * kWave + lane < 20 * N) s_z[it * kWave + lane + (it * kWave + lane) / 20] = zr[it];
         wave_lds_sync();
         const int bn = b + stride;  // the next problem's slice, in flight during this one's sums
         if (bn < P.B) {
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(4 * kWave) void k_objective_shared(BatchParams P, c
             for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)bn * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
         }
         const int kl = min(lane, N - 1);
-        const double term = objective_term(s_z + 20 * kl, s_cost + 41 * kl, kl < N - 1);
+        const double term = objective_term(s_z + 21 * kl, s_cost + 41 * kl, kl < N - 1);
         const double J = add_terms_in_order(0.0, (lane < N) ? term : 0.0, s_term, lane);
         if (lane == 0) F[b] = J;
     }
@@ -1061,13 +1066,14 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
     if (p.cost_batch == 1 && p.N <= kWave && p.B >= 4096) {
-        // one shared cost table: persistent four-wave workgroups with the table in LDS (three per CU at N = 40)
-        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + 4 * (20 * p.N + kWave)) * sizeof(double);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
-        const int grid = std::min(256 * per_cu, (p.B + 3) / 4);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_shared), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // one shared cost table: persistent eight-wave workgroups with the table in LDS (two per CU at N = 40)
+        constexpr int W = QLN_OBJ_WAVES;
+        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + W * (21 * p.N + kWave)) * sizeof(double);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16 / W, (size_t)(160 * 1024) / lds));
+        const int grid = std::min(256 * per_cu, (p.B + W - 1) / W);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_shared<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_objective_shared, dim3(grid), dim3(4 * kWave), lds, stream, p, Z, f);
+        hipLaunchKernelGGL(k_objective_shared<W>, dim3(grid), dim3(W * kWave), lds, stream, p, Z, f);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
