@@ -493,3 +493,22 @@ def test_eval_all_gives_the_bits_of_the_separate_entry_points(B, N, ragged, fmt)
     assert not torch.isnan(f).any()
     ref = oracle_batch(batch, nlp, want_c=False, want_j=False, want_f=True, want_grad=True)
     assert np.array_equal(f.cpu().numpy(), ref["f"])  # and the objective is bit-identical to the oracle
+
+
+@pytest.mark.parametrize("N,kt,im", [(64, 20, 1), (63, 33, 2), (2, 2, 1), (17, 6, 1)])
+def test_shared_cost_table_kernels_at_their_size_limits(N, kt, im):
+    """A batch of >= 4 096 problems that shares one cost table runs eval_f / grad_f! through the shared-table kernels
+    (k_objective_shared, k_objective_gradient_shared: table in LDS, persistent workgroups) for N <= 64: objective and
+    gradient of EVERY problem bit-identical to the oracle at the horizon limits of those kernels."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    B = 4096 + 3
+    batch = PG.make_batch(B, N, kt, im, seed=N)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z = nlp.upload_Z(batch.Z)
+    f, g = nlp.eval_f(Z), nlp.grad_f(Z)
+    torch.cuda.synchronize()
+    ref = oracle_batch(batch, nlp, want_c=False, want_j=False, want_f=True, want_grad=True, nthreads=8)
+    assert np.array_equal(f.cpu().numpy(), ref["f"])
+    assert np.array_equal(g.cpu().numpy().reshape(B, -1)[:, : nlp.n_nlp], ref["grad"].reshape(B, -1)[:, : nlp.n_nlp])
