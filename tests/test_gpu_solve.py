@@ -228,3 +228,21 @@ def test_tiny_and_chunk_boundary_horizons_terminate(N, kt, feasible):
         ci = nlp.cinds(b)
         seg = nlp.split_c(c, b)
         assert np.all(seg[:15] == 0.0) and np.all(seg[ci[2][0] - 1 : ci[2][1]] == 0.0)
+
+
+def test_both_register_budgets_of_the_solver_kernel_give_the_same_bits():
+    """k_al_ilqr is compiled twice (one or two waves per SIMD, chosen by the batch size: B > 1 024 takes the second): the
+    same problems solved in a batch of 1 024 and as the first 1 024 of a batch of 1 100 must come out bit-identical --
+    what a problem's solution is does not depend on how many others were solved beside it."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    big = PG.make_batch(1100, 40, 14, 1, seed=17, noise=0.0)
+    out = []
+    for nb in (1024, 1100):
+        nlp = HybridNLP(big.model, big.obj, big.init_mode[:nb], big.k_trans[:nb], big.N, big.x0[:nb], big.xf[:nb])
+        Z, info = nlp.solve(nlp.initial_guess())
+        torch.cuda.synchronize()
+        out.append((Z.view(nb, -1)[:1024].clone(), info[:1024, :10].clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
