@@ -411,6 +411,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
     // where a problem's time goes: s_memtime ticks per phase, reported in info[10..14]
     unsigned long long tk_refresh = 0, tk_blocks = 0, tk_sweep = 0, tk_roll = 0, tk_accept = 0, tk0;
 #define QLN_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tk0; tk0 = t_; } while (0)
+#ifdef QLN_SWEEP_STAMPS  // tuning build only: info[10..14] = the five phases of a sweep knot instead of the five phases of an iteration
+    unsigned long long sw0 = 0;
+#define QLN_SWEEP_BEGIN() sw0 = __builtin_amdgcn_s_memtime()
+#define QLN_SWEEP_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - sw0; sw0 = t_; } while (0)
+#define QLN_ITER_TICK(acc) do { tk0 = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QLN_SWEEP_BEGIN() do {} while (0)
+#define QLN_SWEEP_TICK(acc) do {} while (0)
+#define QLN_ITER_TICK(acc) QLN_TICK(acc)
+#endif
     double rho = S.rho0, mu = mu0;
     double prev_viol = INFINITY;
     double J_cur = 0.0, viol = INFINITY, last_alpha = 0.0;
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             tk0 = __builtin_amdgcn_s_memtime();
             refresh(rho, J_cur, viol);
             ++iters;
-            QLN_TICK(tk_refresh);
+            QLN_ITER_TICK(tk_refresh);
             // ---- step blocks of every knot (lane = knot), closed form, to the scratch ----
             for (int k0 = 0; k0 < N - 1; k0 += kWave) {
                 const int k = k0 + lane;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             }
             __threadfence();  // the entries are read back by other lanes of this wave
             wave_lds_sync();
-            QLN_TICK(tk_blocks);
+            QLN_ITER_TICK(tk_blocks);
 
             // ---- backward Riccati sweep ----
             // LDS matrices of the sweep have a row stride of 16: an entry index splits into (row, column) by a shift and a
@@ -564,6 +574,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 // integer operations each; hoisted out of the knot loop they would occupy (and spill) registers instead
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
+                QLN_SWEEP_BEGIN();
                 const double* kn = L.kn + kKn * k;
                 const double w = kn[KN_W];
                 const double v0 = pf_e0, v1 = pf_e1, recD = pf_D, recd = pf_d;
@@ -600,6 +611,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     L.Hd[i] = hi;
                 }
                 wave_lds_sync();
+                QLN_SWEEP_TICK(tk_refresh);
                 const double h12 = (k >= 1) ? -rho * (act(kn[KN_T0 + 0]) - act(kn[KN_T0 + 1])) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
                 const double hfc = (k == N - 2) ? rho : 0.0;                              // d2/d(F1y)d(F2y)
                 // The products of the sweep use the structure of the step blocks instead of dense 15-term sums (see
@@ -614,17 +626,23 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     const double a0 = L.A[16 * cc], a2 = (c == 2) ? 0.0 : L.A[30 + cc], a9 = (c == 9) ? 0.0 : L.A[135 + cc];
                     const double ac = (cp >= 0) ? L.A[15 * cp + c] : 0.0;
                     const int cq = max(cp, 0);
+                    // the four passes are independent: every lane loads (clamped row / column, always inside P) and only the
+                    // stores are predicated, so that the LDS reads of all passes are in flight together instead of one
+                    // exec-masked pass (and its waits) after the other
+                    double tv[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const double* pr = L.P + kLd * min((ln >> 4) + 4 * it, 14);
+                        tv[it] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[cc] * a0)));
+                    }
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
-                        if (r < 15 && cv) {
-                            const double* pr = L.P + kLd * r;
-                            L.T[kLd * r + c] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[c] * a0)));
-                        }
+                        if (r < 15 && cv) L.T[kLd * r + c] = tv[it];
                     }
                 }
-                if (ln < 60) {
-                    const int r = ln >> 2, j = ln & 3;
+                {
+                    const int r = min(ln >> 2, 14), j = ln & 3;
                     const double* pr = L.P + kLd * r;
                     int rows[6];
                     b_rows(j, rows);
@@ -638,29 +656,38 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         ah = fma(pr[ic], bv, ah);
                     }
                     ah = quad_sum(ah);
-                    L.S[5 * r + j] = acc;
-                    if (j == 0) L.S[5 * r + 4] = ah;
+                    if (ln < 60) {
+                        L.S[5 * r + j] = acc;
+                        if (j == 0) L.S[5 * r + 4] = ah;
+                    }
                 }
                 wave_lds_sync();
+                QLN_SWEEP_TICK(tk_blocks);
                 // ---- [Qxx | Qx] = [Hxx | gx] + A'[T | pv] ----
                 {
                     const int c = ln & 15;
                     const double t2 = L.T[2 * kLd + c], t9 = L.T[9 * kLd + c];
+                    double qv[4];  // as above: loads of all four passes unconditional (row clamped), stores predicated
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = min((ln >> 4) + 4 * it, 14);
+                        const int rp = a_coupling(r), rq = max(rp, 0);
+                        const double gr = L.g[r], hr = L.Hd[r];
+                        const double a0 = L.A[16 * r], a2v = L.A[30 + r], a9v = L.A[135 + r], acv = L.A[15 * rq + r];
+                        const double tr = L.T[kLd * r + c], tq = L.T[kLd * rq + c];
+                        double acc = (c == 15) ? gr : ((r == c) ? hr : 0.0);
+                        if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
+                        const double a2 = (r == 2) ? 0.0 : a2v, a9 = (r == 9) ? 0.0 : a9v, ac = (rp >= 0) ? acv : 0.0;
+                        acc = fma(a0, tr, acc);
+                        acc = fma(a2, t2, acc);
+                        acc = fma(a9, t9, acc);
+                        acc = fma(ac, tq, acc);
+                        qv[it] = acc;
+                    }
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
-                        if (r < 15) {
-                            const int rp = a_coupling(r);
-                            double acc = (c == 15) ? L.g[r] : ((r == c) ? L.Hd[r] : 0.0);
-                            if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
-                            const double a0 = L.A[16 * r], a2 = (r == 2) ? 0.0 : L.A[30 + r], a9 = (r == 9) ? 0.0 : L.A[135 + r];
-                            const double ac = (rp >= 0) ? L.A[15 * rp + r] : 0.0;
-                            acc = fma(a0, L.T[kLd * r + c], acc);
-                            acc = fma(a2, t2, acc);
-                            acc = fma(a9, t9, acc);
-                            acc = fma(ac, L.T[kLd * max(rp, 0) + c], acc);
-                            L.Qxx[kLd * r + c] = acc;
-                        }
+                        if (r < 15) L.Qxx[kLd * r + c] = qv[it];
                     }
                 }
                 // ---- [Qux | Qu] = [0 | gu] + B'[T | pv]: force rows (ln = 16 j + c), then the h row in quads ----
@@ -686,19 +713,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     if (p == 0) L.Qux[4 * kLd + c] = ah + ((c == 15) ? L.g[19] : 0.0);
                 }
                 // ---- Quu = Huu + B'S + mu I: the force rows (and, by symmetry, the h row), then (h, h) in a quad ----
-                if (ln < 32) {
-                    const int j = ln >> 3, c = ln & 7;
-                    if (c < 5) {
-                        int rows[6];
-                        b_rows(j, rows);
-                        double acc = (j == c) ? L.Hd[15 + j] + mu : 0.0;
-                        if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
+                {   // every lane runs both parts on clamped indices (no divergent branches around the LDS reads); lanes 0-31
+                    // keep the force rows, the quad of lanes 32-35 keeps (h, h)
+                    const int j = (ln >> 3) & 3, c = min(ln & 7, 4);
+                    int rows[6];
+                    b_rows(j, rows);
+                    const double hdj = L.Hd[15 + j], hd19 = L.Hd[19];
+                    double acc = (j == c) ? hdj + mu : 0.0;
+                    if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.S[5 * rows[q] + c], acc);
-                        L.Quu[5 * j + c] = acc;
-                        if (c == 4) L.Quu[20 + j] = acc;
-                    }
-                } else if (ln < 36) {
+                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.S[5 * rows[q] + c], acc);
                     const int p = ln & 3;
                     double ah = 0.0;
 #pragma unroll
@@ -708,9 +732,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         ah = fma(bv, L.S[5 * ic + 4], ah);
                     }
                     ah = quad_sum(ah);
-                    if (p == 0) L.Quu[24] = ah + L.Hd[19] + mu + h_prox;  // + the proximal weight on the step length (see SolveParams)
+                    if (ln < 32 && (ln & 7) < 5) {
+                        L.Quu[5 * j + c] = acc;
+                        if (c == 4) L.Quu[20 + j] = acc;
+                    }
+                    if (ln == 32) L.Quu[24] = ah + hd19 + mu + h_prox;  // + the proximal weight on the step length (see SolveParams)
                 }
                 wave_lds_sync();
+                QLN_SWEEP_TICK(tk_sweep);
                 // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every ln alike
                 double q[5][5], l[5][5], dd[5], dinv[5];
 #pragma unroll
@@ -794,6 +823,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int i = 0; i < 5; ++i) Kg[(int64_t)kKg * k + 16 * i + ln] = (ln < 15) ? kc[i] : dff[i];
                 }
                 wave_lds_sync();
+                QLN_SWEEP_TICK(tk_roll);
                 // Value function of the knot: with K = -Quu_ff^-1 Qux_f on the free controls (zero rows for a clamped h) and
                 // d the matching feed-forward, K'(Quu K + Qux) and K'(Quu d + Qu) vanish identically, so
                 //     P <- sym(Qxx + Qux' K),   pv <- Qx + Qux' d
@@ -810,18 +840,22 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         qc[i] = L.Qux[kLd * i + cc];
                         kcol[i] = L.K[kLd * i + cc];
                     }
+                    double pv4[4];  // loads of the four passes unconditional (row clamped), stores predicated
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = min((ln >> 4) + 4 * it, 14);
+                        double acc = L.Qxx[kLd * r + cc], act_ = L.Qxx[kLd * cc + r];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            acc = fma(L.Qux[kLd * i + r], kcol[i], acc);
+                            act_ = fma(qc[i], L.K[kLd * i + r], act_);
+                        }
+                        pv4[it] = 0.5 * (acc + act_);
+                    }
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (ln >> 4) + 4 * it;
-                        if (r < 15 && cv) {
-                            double acc = L.Qxx[kLd * r + c], act_ = L.Qxx[kLd * c + r];
-#pragma unroll
-                            for (int i = 0; i < 5; ++i) {
-                                acc = fma(L.Qux[kLd * i + r], kcol[i], acc);
-                                act_ = fma(qc[i], L.K[kLd * i + r], act_);
-                            }
-                            L.P[kLd * r + c] = 0.5 * (acc + act_);
-                        }
+                        if (r < 15 && cv) L.P[kLd * r + c] = pv4[it];
                     }
                 }
                 if (ln < 15) {
@@ -831,6 +865,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     L.T[kLd * ln + 15] = acc;
                 }
                 wave_lds_sync();
+                QLN_SWEEP_TICK(tk_accept);
             }
             if (!pd_ok) {
                 mu = fmin(mu * 10.0, mu_max);
@@ -841,7 +876,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 continue;
             }
 
-            QLN_TICK(tk_sweep);
+            QLN_ITER_TICK(tk_sweep);
             __threadfence();  // the gains written during the sweep are read back by the roll-out lanes
             // ---- forward: one closed-loop roll-out per step length, lane a < 16 tries alpha = 2^-a and keeps its
             //      trajectory in the scratch, so that the accepted one need not be rolled out again.  Only the
@@ -948,7 +983,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 for (int off = kAlphas; off < kWave; off <<= 1) J += __shfl_xor(J, off, kWave);
                 J_try = J;
             }
-            QLN_TICK(tk_roll);
+            QLN_ITER_TICK(tk_roll);
             // the best of the sixteen candidates, if any lowers the cost (all were computed anyway: one lane each)
             double J_best = ((lane < kAlphas) && (J_try == J_try) && (J_try < J_cur)) ? J_try : INFINITY;
             int a_star = lane;
@@ -984,7 +1019,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 }
             }
             wave_lds_sync();
-            QLN_TICK(tk_accept);
+            QLN_ITER_TICK(tk_accept);
             mu = fmax(mu / 3.0, mu_min);
             const double dJ = J_cur - J_new;
             if (dJ < inner_tol * (1.0 + fabs(J_new))) break;
