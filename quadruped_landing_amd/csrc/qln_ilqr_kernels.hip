@@ -48,6 +48,11 @@ constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85
 constexpr int kKn = 9;         // per-knot scalars kept in LDS
 constexpr int kLd = 17;        // leading dimension of the sweep's LDS matrices: 16 columns + 1 (a stride of 16 doubles puts a column in two LDS banks)
 constexpr int kKg = 80;        // doubles per knot of the feedback law in the scratch: 5 rows of [15 gains, feed-forward]
+// Entries of the LDS images of A (15x15, stride 15) and B (15x5) that no step block ever has (step_structure_ok below): they hold
+// 0.0 for the whole sweep.  "value or zero" is then ONE read with a selected address -- hipcc turns a select between a loaded
+// value and a constant into a branch around the load, with a wait of its own, and the reads of a phase stop overlapping.
+constexpr int kAZero = 1;      // A(0, 1)
+constexpr int kBZero = 5;      // B(1, 0)
 
 // per-knot scalars (lane = knot phase -> backward sweep)
 enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g); the row is active where t > 0 */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8 };
@@ -71,6 +76,11 @@ __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_quad_perm<0xB1>(v);  // quad_perm [1, 0, 3, 2]
     v += dpp_quad_perm<0x4E>(v);  // quad_perm [2, 3, 0, 1]
     return v;
+}
+// the value lane `src` holds, in every lane (wave-uniform: it lives in scalar registers)
+__device__ __forceinline__ double read_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
@@ -183,6 +193,7 @@ __device__ __forceinline__ void step_forward(const BatchParams& P, int k, int kt
     }
 }
 
+
 // The same knot in closed form, for the TRIAL roll-outs.  With zero-order-hold forces every acceleration but the body's
 // angular one is constant over the step, and RK4 reproduces p+ = p + h v + h^2 a/2, v+ = v + h a, and the cubic / quartic
 // in h for omega / theta (file header of qln_kernels.hip) up to rounding: 1.3e-15 against the RK4 step on random states.
@@ -256,6 +267,7 @@ constexpr bool step_structure_ok() {
     return true;
 }
 static_assert(step_structure_ok(), "the sparse products of the Riccati sweep cover every possible non-zero of a step block");
+static_assert(!step_union_present(0, 1) && !step_union_present(1, 15), "the zero slots of the A / B images are outside the union pattern");
 
 struct Lds {
     double *X, *U, *K, *leq, *kn, *P, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *g, *Hd;
@@ -569,48 +581,59 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 cd = rec[20 + min(lane, 19)];
             };
             prefetch(N - 2, pf_e0, pf_e1, pf_D, pf_d);
-            for (int k = N - 2; k >= 0 && pd_ok; --k) {
-                // the lane index, opaque to loop-invariant code motion: the LDS addresses of the phases below are a few
-                // integer operations each; hoisted out of the knot loop they would occupy (and spill) registers instead
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
-                QLN_SWEEP_BEGIN();
+            // where this lane's entries of a step block go in [A | B] (constant over the knots)
+            const int m0 = L.map[lane], m1 = L.map[min(lane + 64, kStepUnion - 1)];
+            // What knot k needs in LDS before its products start: A (15x15), B (15x5) scattered from the prefetched entries, the
+            // stage gradient (20) and the diagonal of the Gauss-Newton Hessian.  None of it depends on the knot behind, so it
+            // is staged one knot AHEAD -- for knot k-1 while knot k factors Quu, a chain of dependent FP64 operations that
+            // leaves the issue slots empty -- and is off the sweep's critical path.  No branches around LDS reads: the
+            // knot's scalars are read by every lane (one address), the three special entries are selects.
+            auto stage_knot = [=](int k, int ln, double v0, double v1, double recD, double recd) {
+                L.A[m0] = v0;
+                L.A[m1] = v1;  // lanes past the end of the pattern repeat its last entry: the same value to the same address
                 const double* kn = L.kn + kKn * k;
                 const double w = kn[KN_W];
+                const double t0 = kn[KN_T0 + 0], t1 = kn[KN_T0 + 1], t2 = kn[KN_T0 + 2], t3 = kn[KN_T0 + 3], t4 = kn[KN_T0 + 4],
+                             t5 = kn[KN_T0 + 5], cq = kn[KN_CQ], ell = kn[KN_ELL];
+                const double lfc = L.leq[15];
+                const int i = min(ln, 19);
+                const double zi = *((i < 15) ? L.X + 15 * k + i : L.U + 5 * k + (i - 15));
+                double gi = w * (recD * zi + recd);
+                double hi = w * recD;
+                // selects, not branches: the block stays straight-line code that the scheduler can weave into the factorisation
+                const bool live = k >= 1;  // x_1 = x0 is data: its inequality rows are not live
+                const double g1 = gi + (-t0 - t1 - t4), h1 = hi + rho * (act(t0) + act(t1) + act(t4));
+                const double g2 = gi + ((t0 - t1) * cq + t2 - t3), h2 = hi + rho * ((act(t0) + act(t1)) * cq * cq + act(t2) + act(t3));
+                const double g3 = gi + -t5, h3 = hi + rho * act(t5);
+                gi = (live && i == 1) ? g1 : (live && i == 2) ? g2 : (live && i == 3) ? g3 : gi;
+                hi = (live && i == 1) ? h1 : (live && i == 2) ? h2 : (live && i == 3) ? h3 : hi;
+                const bool fc = (k == N - 2) && (i == 16 || i == 18);
+                gi = fc ? gi + lfc : gi;
+                hi = fc ? hi + rho : hi;
+                gi = (exact_h && i == 19) ? gi + ell : gi;  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
+                // lanes 20 .. 63 have nothing to store: they write into the body of T, which is dead between the products that read
+                // it and the next knot's T = P A (the vector in its sixteenth column is not touched)
+                *((ln < 20) ? L.g + i : L.T + (ln & 7)) = gi;
+                *((ln < 20) ? L.Hd + i : L.T + kLd + (ln & 7)) = hi;
+            };
+            stage_knot(N - 2, lane, pf_e0, pf_e1, pf_D, pf_d);
+            if (N >= 3) prefetch(N - 3, pf_e0, pf_e1, pf_D, pf_d);
+            wave_lds_sync();
+            for (int k = N - 2; k >= 0 && pd_ok; --k) {
+                // the lane index, opaque to loop-invariant code motion in the two-waves-per-SIMD build: the LDS addresses of the
+                // phases below are a few integer operations each; hoisted out of the knot loop they would occupy (and spill)
+                // registers there.  The one-wave-per-SIMD build has 512 registers and lets them be hoisted: its sweep is a
+                // fifth shorter for it (310 k against 377 k cycles of 39 knots).
+                int ln = lane;
+#ifndef QLN_HOIST_OCC2  // tuning build only
+                if constexpr (OCC == 2) asm volatile("" : "+v"(ln));
+#endif
+                QLN_SWEEP_BEGIN();
+                const double* kn = L.kn + kKn * k;
+                // knot k-1's entries and cost record (requested a knot ago) are staged during this knot's factorisation; knot
+                // k-2's are requested now
                 const double v0 = pf_e0, v1 = pf_e1, recD = pf_D, recd = pf_d;
-                if (k > 0) prefetch(k - 1, pf_e0, pf_e1, pf_D, pf_d);
-                // A (15x15), B (15x5) from the entries
-                L.A[L.map[ln]] = v0;
-                if (ln + 64 < kStepUnion) L.A[L.map[ln + 64]] = v1;
-                // stage gradient (20) and the Gauss-Newton Hessian: diagonal + the (yb, theta) and (F1y, F2y) couplings
-                if (ln < 20) {
-                    const int i = ln;
-                    const double zi = (i < 15) ? L.X[15 * k + i] : L.U[5 * k + (i - 15)];
-                    double gi = w * (recD * zi + recd);
-                    double hi = w * recD;
-                    if (k >= 1) {
-                        if (i == 1) {
-                            gi += -kn[KN_T0 + 0] - kn[KN_T0 + 1] - kn[KN_T0 + 4];
-                            hi += rho * (act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1]) + act(kn[KN_T0 + 4]));
-                        }
-                        if (i == 2) {
-                            gi += (kn[KN_T0 + 0] - kn[KN_T0 + 1]) * kn[KN_CQ] + kn[KN_T0 + 2] - kn[KN_T0 + 3];
-                            hi += rho * ((act(kn[KN_T0 + 0]) + act(kn[KN_T0 + 1])) * kn[KN_CQ] * kn[KN_CQ] + act(kn[KN_T0 + 2]) + act(kn[KN_T0 + 3]));
-                        }
-                        if (i == 3) {
-                            gi += -kn[KN_T0 + 5];
-                            hi += rho * act(kn[KN_T0 + 5]);
-                        }
-                    }
-                    if (k == N - 2 && (i == 16 || i == 18)) {
-                        gi += L.leq[15];
-                        hi += rho;
-                    }
-                    if (exact_h && i == 19) gi += kn[KN_ELL];  // d(h l)/dh, the term grad_f! leaves out (quirk Q2)
-                    L.g[i] = gi;
-                    L.Hd[i] = hi;
-                }
-                wave_lds_sync();
+                if (k > 1) prefetch(k - 2, pf_e0, pf_e1, pf_D, pf_d);
                 QLN_SWEEP_TICK(tk_refresh);
                 const double h12 = (k >= 1) ? -rho * (act(kn[KN_T0 + 0]) - act(kn[KN_T0 + 1])) * kn[KN_CQ] : 0.0;  // d2/d(yb)d(theta)
                 const double hfc = (k == N - 2) ? rho : 0.0;                              // d2/d(F1y)d(F2y)
@@ -623,9 +646,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     const int c = ln & 15, cp = a_coupling(c);
                     const bool cv = c < 15;
                     const int cc = cv ? c : 0;
-                    const double a0 = L.A[16 * cc], a2 = (c == 2) ? 0.0 : L.A[30 + cc], a9 = (c == 9) ? 0.0 : L.A[135 + cc];
-                    const double ac = (cp >= 0) ? L.A[15 * cp + c] : 0.0;
                     const int cq = max(cp, 0);
+                    const double a0 = L.A[16 * cc], a2 = L.A[(c == 2) ? kAZero : 30 + cc], a9 = L.A[(c == 9) ? kAZero : 135 + cc];
+                    const double ac = L.A[(cp >= 0) ? 15 * cq + cc : kAZero];
                     // the four passes are independent: every lane loads (clamped row / column, always inside P) and only the
                     // stores are predicated, so that the LDS reads of all passes are in flight together instead of one
                     // exec-masked pass (and its waits) after the other
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int i = j + 4 * t, ic = min(i, 14);
-                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
                         ah = fma(pr[ic], bv, ah);
                     }
                     ah = quad_sum(ah);
@@ -672,12 +695,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int it = 0; it < 4; ++it) {
                         const int r = min((ln >> 4) + 4 * it, 14);
                         const int rp = a_coupling(r), rq = max(rp, 0);
-                        const double gr = L.g[r], hr = L.Hd[r];
-                        const double a0 = L.A[16 * r], a2v = L.A[30 + r], a9v = L.A[135 + r], acv = L.A[15 * rq + r];
+                        const double a0 = L.A[16 * r], a2 = L.A[(r == 2) ? kAZero : 30 + r], a9 = L.A[(r == 9) ? kAZero : 135 + r];
+                        const double ac = L.A[(rp >= 0) ? 15 * rq + r : kAZero];
                         const double tr = L.T[kLd * r + c], tq = L.T[kLd * rq + c];
-                        double acc = (c == 15) ? gr : ((r == c) ? hr : 0.0);
+                        double acc = *((c == 15) ? L.g + r : (r == c) ? L.Hd + r : L.A + kAZero);
                         if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
-                        const double a2 = (r == 2) ? 0.0 : a2v, a9 = (r == 9) ? 0.0 : a9v, ac = (rp >= 0) ? acv : 0.0;
                         acc = fma(a0, tr, acc);
                         acc = fma(a2, t2, acc);
                         acc = fma(a9, t9, acc);
@@ -706,7 +728,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int i = p + 4 * t, ic = min(i, 14);
-                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
                         ah = fma(bv, L.T[kLd * ic + c], ah);
                     }
                     ah = quad_sum(ah);
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int i = p + 4 * t, ic = min(i, 14);
-                        const double bv = (i < 15) ? L.B[5 * ic + 4] : 0.0;
+                        const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
                         ah = fma(bv, L.S[5 * ic + 4], ah);
                     }
                     ah = quad_sum(ah);
@@ -740,26 +762,47 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 }
                 wave_lds_sync();
                 QLN_SWEEP_TICK(tk_sweep);
+                // knot k-1 is staged here, in the shadow of the factorisation below (see stage_knot): A, B, g, Hd were last read
+                // before the barrier above and are next read after the one that ends this knot
+                stage_knot(max(k - 1, 0), ln, v0, v1, recD, recd);  // (knot 0 is staged twice, with its own data: harmless)
                 // LDL' of Quu (5x5, h last so that the leading 4x4 factor serves the clamped case), every ln alike
-                double q[5][5], l[5][5], dd[5], dinv[5];
+                double q[5][5], l[5][5], dinv[5];
 #pragma unroll
                 for (int r = 0; r < 5; ++r)
 #pragma unroll
                     for (int c = 0; c < 5; ++c) q[r][c] = L.Quu[5 * r + c];
+                // right-hand sides, one per lane: lane j < 15 column j of Qux (its solution is column j of the gains), lanes
+                // 15 .. 63 Qu (the feed-forward) -- ONE solve serves both
+                double y[5], qu[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    y[i] = -L.Qux[kLd * i + min(ln, 15)];
+                    qu[i] = L.Qux[kLd * i + 15];
+                }
+                const double hk = L.U[5 * k + 4];
+                // v[i][j] = l[i][j] d[j] is kept beside l[i][j]: a term of the factorisation is then one fused multiply-add
+                // (l_im v_jm), and 1/d_j is the hardware reciprocal refined by two Newton steps (d_j > 1e-300 is checked:
+                // none of the scaling an IEEE division carries is needed) -- a third of the instructions of the plain form on
+                // the longest dependent chain of a knot.  (Explicit fma: the library is built with -ffp-contract=off for the
+                // evaluator's sake.)
+                double vv[5][5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     double dj = q[j][j];
 #pragma unroll
-                    for (int m = 0; m < j; ++m) dj -= l[j][m] * l[j][m] * dd[m];
+                    for (int m = 0; m < j; ++m) dj = fma(-l[j][m], vv[j][m], dj);
                     if (!(dj > 1e-300)) pd_ok = false;
-                    dd[j] = dj;
-                    dinv[j] = 1.0 / dj;
+                    double rj = __builtin_amdgcn_rcp(dj);
+                    rj = fma(fma(-dj, rj, 1.0), rj, rj);
+                    rj = fma(fma(-dj, rj, 1.0), rj, rj);
+                    dinv[j] = rj;
 #pragma unroll
                     for (int i = j + 1; i < 5; ++i) {
                         double v = q[i][j];
 #pragma unroll
-                        for (int m = 0; m < j; ++m) v -= l[i][m] * l[j][m] * dd[m];
-                        l[i][j] = v * dinv[j];
+                        for (int m = 0; m < j; ++m) v = fma(-l[i][m], vv[j][m], v);
+                        vv[i][j] = v;
+                        l[i][j] = v * rj;
                     }
                 }
                 if (!pd_ok) break;  // wave-uniform: every ln factors the same matrix
@@ -769,7 +812,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int i = 0; i < 5; ++i) {
                         if (i < n) {
 #pragma unroll
-                            for (int m = 0; m < i; ++m) y[i] -= l[i][m] * y[m];
+                            for (int m = 0; m < i; ++m) y[i] = fma(-l[i][m], y[m], y[i]);
                         }
                     }
 #pragma unroll
@@ -780,47 +823,37 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         if (i < n) {
 #pragma unroll
                             for (int m = i + 1; m < 5; ++m)
-                                if (m < n) y[i] -= l[m][i] * y[m];
+                                if (m < n) y[i] = fma(-l[m][i], y[m], y[i]);
                         }
                     }
                 };
-                // feed-forward (every ln), with the box on h: clamp, then re-solve the free 4x4
-                double qu[5], dff[5];
+                ldl_solve(y, 5);
+                // the feed-forward is lane 15's solution (wave-uniform from here on); the box on h: clamp, then the free 4x4
+                // is solved again -- by every lane for its own right-hand side
+                double dff[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    qu[i] = L.Qux[kLd * i + 15];
-                    dff[i] = -qu[i];
-                }
-                ldl_solve(dff, 5);
-                const double hk = L.U[5 * k + 4];
+                for (int i = 0; i < 5; ++i) dff[i] = read_lane(y[i], 15);
                 const double lo = h_lo - hk, hi = h_hi - hk;
                 const bool clamped = (dff[4] < lo) || (dff[4] > hi);
                 if (clamped) {
                     const double hc = fmin(fmax(dff[4], lo), hi);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dff[i] = -(qu[i] + q[i][4] * hc);
-                    dff[4] = 0.0;
-                    ldl_solve(dff, 4);
+                    for (int i = 0; i < 4; ++i) y[i] = (ln < 15) ? -L.Qux[kLd * i + min(ln, 14)] : -(qu[i] + q[i][4] * hc);
+                    y[4] = 0.0;
+                    ldl_solve(y, 4);
+                    y[4] = 0.0;  // gains: the row of a clamped h is zero
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dff[i] = read_lane(y[i], 15);
                     dff[4] = hc;
                 }
-                // gains: ln j < 15 solves column j
-                double kc[5] = {0, 0, 0, 0, 0};
+                // gains: ln j < 15 holds column j
                 if (ln < 15) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) kc[i] = -L.Qux[kLd * i + ln];
-                    if (clamped) {
-                        kc[4] = 0.0;
-                        ldl_solve(kc, 4);
-                        kc[4] = 0.0;
-                    } else {
-                        ldl_solve(kc, 5);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) L.K[kLd * i + ln] = kc[i];
+                    for (int i = 0; i < 5; ++i) L.K[kLd * i + ln] = y[i];
                 }
                 if (ln < 16) {  // row i of the knot's record: 15 gains, then the feed-forward d_i
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) Kg[(int64_t)kKg * k + 16 * i + ln] = (ln < 15) ? kc[i] : dff[i];
+                    for (int i = 0; i < 5; ++i) Kg[(int64_t)kKg * k + 16 * i + ln] = (ln < 15) ? y[i] : dff[i];
                 }
                 wave_lds_sync();
                 QLN_SWEEP_TICK(tk_roll);
