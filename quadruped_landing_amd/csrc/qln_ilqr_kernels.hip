@@ -569,7 +569,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             }
             // A and B hold zeros wherever the union pattern has no entry: written once, the per-knot scatter below touches
             // exactly the pattern's 85 positions.  What a knot needs from global memory -- its step-block entries and its
-            // cost record -- is requested one knot ahead, so that the L2 round trip is off the sweep's dependency chain.
+            // cost record -- is requested two knots ahead (it is staged one knot ahead, below), so that the L2 round trip is off
+            // the sweep's dependency chain.
             for (int e = lane; e < 300; e += kWave) L.A[e] = 0.0;
             double pf_e0, pf_e1, pf_D, pf_d;
             auto prefetch = [=](int k, double& e0, double& e1, double& cD, double& cd) {
