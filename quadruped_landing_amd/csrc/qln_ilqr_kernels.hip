@@ -30,6 +30,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 
 namespace qln {
 namespace {
@@ -76,6 +77,43 @@ __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_quad_perm<0xB1>(v);  // quad_perm [1, 0, 3, 2]
     v += dpp_quad_perm<0x4E>(v);  // quad_perm [2, 3, 0, 1]
     return v;
+}
+// lane I of each row of sixteen lanes, in every lane of that row (DPP row_newbcast: one v_mov_b64_dpp, no LDS, no wait).
+// The source lane must be enabled.
+template <int I>
+__device__ __forceinline__ double row_bcast(double v) {
+    static_assert(I >= 0 && I < 16, "a lane of the row");
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + I, 0xf, 0xf, false);
+}
+// u[j] += K[j](lane I of the row) * dx for the five rows of a feedback law: v_fmac_f64 with the DPP operand -- the broadcast
+// costs no instruction of its own (hipcc does not fold a v_mov_b64_dpp into the multiply-add, hence the assembly; fused like
+// fma()).  FIRST: the block opens with the wait states a DPP operand needs after its register or EXEC was last written by
+// a VALU instruction -- the compiler does not see through inline assembly to insert them.
+template <int I, bool FIRST>
+__device__ __forceinline__ void fmac5_row_bcast(double (&u)[5], const double (&K)[5], double dx) {
+    static_assert(I >= 0 && I < 16, "a lane of the row");
+    if constexpr (FIRST) {
+        asm("s_nop 4\n\t"
+            "v_fmac_f64_dpp %0, %5, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %3, %8, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %4, %9, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+            : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4])
+            : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(dx), "n"(I));
+    } else {
+        asm("v_fmac_f64_dpp %0, %5, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %3, %8, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %4, %9, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+            : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4])
+            : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(dx), "n"(I));
+    }
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
 }
 // the value lane `src` holds, in every lane (wave-uniform: it lives in scalar registers)
 __device__ __forceinline__ double read_lane(double v, int src) {
@@ -914,10 +952,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             __threadfence();  // the gains written during the sweep are read back by the roll-out lanes
             // ---- forward: one closed-loop roll-out per step length, lane a < 16 tries alpha = 2^-a and keeps its
             //      trajectory in the scratch, so that the accepted one need not be rolled out again.  Only the
-            //      state recursion is serial.  The other 48 lanes work for the sixteen: all 64 fetch the next knot's
-            //      gains (coalesced) while the sixteen take their step, handed over through LDS (S and Qux of the sweep:
-            //      80 doubles each); and the merit of the trial trajectories is evaluated three knots at a time by the
-            //      three idle lane groups, from (x_k, u_k) the roll-out lanes leave in LDS (the sweep's P, A, T, Qxx are
+            //      state recursion is serial.  A knot's feedback law lies across the sixteen lanes' registers and reaches a
+            //      lane by DPP row broadcast (below); the merit of the trial trajectories is evaluated three knots at a time by
+            //      the three idle lane groups, from (x_k, u_k) the roll-out lanes leave in LDS (the sweep's P, A, T, Qxx are
             //      free now) -- nothing of a trial trajectory is read back from memory but the accepted one.
             double J_try = INFINITY;
             {
@@ -931,18 +968,19 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 double J = 0.0;
 #pragma unroll
                 for (int i = 0; i < 15; ++i) x[i] = L.X[i];
-                {
-                    const double g0 = Kg[lane], g1 = Kg[64 + (lane & 15)];
-                    L.S[lane] = g0;
-                    if (lane < 16) L.S[64 + lane] = g1;
-                }
-                // the gains of knot k+1 are requested during knot k-1 and parked in LDS at the end of knot k: a whole knot
-                // of arithmetic between a load and its first use
-                double g0, g1;
-                {
-                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(1, N - 2);
-                    g0 = kp[lane], g1 = kp[64 + (lane & 15)];
-                }
+                // The feedback law of a knot -- 5 rows of [15 gains, feed-forward] -- is held across a row of sixteen lanes, one
+                // register per row of the law: lane i of the roll-out lanes' row has K[j][i] (i = 15: d_j).  A roll-out lane gets
+                // the entry it needs by a DPP row broadcast (one v_mov_b64_dpp each): no LDS tile for the gains, no batches of
+                // LDS reads each waited for in turn -- those were a quarter of a roll-out knot.  The next knot's law is requested
+                // a knot ahead (L2-resident scratch).
+                static_assert(kAlphas == 16, "the roll-out lanes are one DPP row");
+                double Kr[5], Kn[5];
+                auto load_gains = [=](int k, double (&K)[5]) {
+                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(k, N - 2) + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) K[j] = kp[16 * j];
+                };
+                load_gains(0, Kr);
                 // a helper lane's multipliers are requested a batch ahead (global scratch)
                 double lr[kIneq];
                 auto fetch_lam = [=](int kk, double (&lo)[kIneq]) {
@@ -953,20 +991,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 fetch_lam(grp, lr);
                 wave_lds_sync();
                 for (int k = 0; k < N - 1; ++k) {
-                    const double* kc = (k & 1) ? L.Qux : L.S;
-                    double* kx = (k & 1) ? L.S : L.Qux;
-                    const double* __restrict__ kp = Kg + (int64_t)kKg * min(k + 2, N - 2);
-                    const double h0 = kp[lane], h1 = kp[64 + (lane & 15)];
+                    load_gains(k + 1, Kn);  // a whole knot of arithmetic between the request and the first use
                     const int slot = k % kGroups;
                     if (lane < kAlphas) {
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * kc[16 * j + 15];
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) {
+                        for (int j = 0; j < 5; ++j) u[j] = L.U[5 * k + j] + alpha * row_bcast<15>(Kr[j]);
+                        static_for(std::make_integer_sequence<int, 15>{}, [&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
                             const double dx = x[i] - L.X[15 * k + i];
-#pragma unroll
-                            for (int j = 0; j < 5; ++j) u[j] = fma(kc[16 * j + i], dx, u[j]);
-                        }
+                            fmac5_row_bcast<i, i == 0>(u, Kr, dx);
+                        });
                         u[4] = fmin(fmax(u[4], h_lo), h_hi);
                         double* sl = slots + (slot * kAlphas + a) * 20;
 #pragma unroll
@@ -983,9 +1017,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             tz[kAlphas * (20 * (k + 1) + i)] = xn[i];
                         }
                     }
-                    kx[lane] = g0;
-                    if (lane < 16) kx[64 + lane] = g1;
-                    g0 = h0, g1 = h1;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) Kr[j] = Kn[j];
                     wave_lds_sync();
                     if (slot == kGroups - 1 || k == N - 2) {  // a batch of knots kb .. k is complete (wave-uniform)
                         const int kb = k - slot, kk = kb + grp;
