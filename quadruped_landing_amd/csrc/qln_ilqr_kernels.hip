@@ -624,9 +624,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             const int m0 = L.map[lane], m1 = L.map[min(lane + 64, kStepUnion - 1)];
             // What knot k needs in LDS before its products start: A (15x15), B (15x5) scattered from the prefetched entries, the
             // stage gradient (20) and the diagonal of the Gauss-Newton Hessian.  None of it depends on the knot behind, so it
-            // is staged one knot AHEAD -- for knot k-1 while knot k factors Quu, a chain of dependent FP64 operations that
-            // leaves the issue slots empty -- and is off the sweep's critical path.  No branches around LDS reads: the
-            // knot's scalars are read by every lane (one address), the three special entries are selects.
+            // is staged one knot AHEAD -- for knot k-1 inside the phase in which knot k factors Quu -- and has no barrier and no
+            // LDS round trip of its own on the sweep's critical path.  No branches around LDS reads: the knot's scalars are
+            // read by every lane (one address), the three special entries are selects.
             auto stage_knot = [=](int k, int ln, double v0, double v1, double recD, double recd) {
                 L.A[m0] = v0;
                 L.A[m1] = v1;  // lanes past the end of the pattern repeat its last entry: the same value to the same address
