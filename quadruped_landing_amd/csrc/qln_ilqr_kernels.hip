@@ -87,8 +87,9 @@ __device__ __forceinline__ double row_bcast(double v) {
 }
 // u[j] += K[j](lane I of the row) * dx for the five rows of a feedback law: v_fmac_f64 with the DPP operand -- the broadcast
 // costs no instruction of its own (hipcc does not fold a v_mov_b64_dpp into the multiply-add, hence the assembly; fused like
-// fma()).  FIRST: the block opens with the wait states a DPP operand needs after its register or EXEC was last written by
-// a VALU instruction -- the compiler does not see through inline assembly to insert them.
+// fma()).  The block opens with the wait states an instruction with a DPP operand needs after one of its registers (two) or
+// EXEC (five: FIRST, the block that follows the branch into the roll-out lanes' code) was last written by a VALU
+// instruction -- the compiler does not see through inline assembly to insert them.
 template <int I, bool FIRST>
 __device__ __forceinline__ void fmac5_row_bcast(double (&u)[5], const double (&K)[5], double dx) {
     static_assert(I >= 0 && I < 16, "a lane of the row");
@@ -102,7 +103,8 @@ __device__ __forceinline__ void fmac5_row_bcast(double (&u)[5], const double (&K
             : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4])
             : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(dx), "n"(I));
     } else {
-        asm("v_fmac_f64_dpp %0, %5, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %5, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %3, %8, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
