@@ -682,6 +682,12 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 // step_structure_ok above): A = diagonal + rows 2 (theta) and 9 (omega) + the six position <- velocity
                 // couplings (c-7, c); a force column of B has six rows; only the h column of B is dense -- its 15-term
                 // sums are split over the four lanes of a quad (terms i = p, p+4, p+8, p+12) and added up by DPP.
+                // In the one-wave-per-SIMD build every phase below does ALL its reads and arithmetic first and its (predicated) stores
+                // last: a predicated store ends a basic block, and hipcc does not move the reads of one product above the stores
+                // of another -- written product by product, a phase is a chain of read / wait / store segments.  The
+                // two-waves-per-SIMD build keeps the product-by-product order: with all reads of a phase in flight its 256
+                // registers overflow and the spills land in the roll-out loop (measured: sweep -9 %, roll-outs +15..48 %).
+                constexpr bool kStoresLast = (OCC == 1);
                 // ---- T = P A (entry (r, c): ln keeps c, r = (ln >> 4) + 4 pass), S = P B ----
                 {
                     const int c = ln & 15, cp = a_coupling(c);
@@ -699,36 +705,38 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         const double* pr = L.P + kLd * min((ln >> 4) + 4 * it, 14);
                         tv[it] = fma(pr[cq], ac, fma(pr[9], a9, fma(pr[2], a2, pr[cc] * a0)));
                     }
+                    auto store_T = [&]() {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int r = (ln >> 4) + 4 * it;
-                        if (r < 15 && cv) L.T[kLd * r + c] = tv[it];
-                    }
-                }
-                {
-                    const int r = min(ln >> 2, 14), j = ln & 3;
-                    const double* pr = L.P + kLd * r;
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = (ln >> 4) + 4 * it;
+                            if (r < 15 && cv) L.T[kLd * r + c] = tv[it];
+                        }
+                    };
+                    if constexpr (!kStoresLast) store_T();
+                    const int rs = min(ln >> 2, 14), js = ln & 3;
+                    const double* ps = L.P + kLd * rs;
                     int rows[6];
-                    b_rows(j, rows);
-                    double acc = 0.0, ah = 0.0;
+                    b_rows(js, rows);
+                    double accS = 0.0, ahS = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) acc = fma(pr[rows[q]], L.B[5 * rows[q] + j], acc);
+                    for (int q = 0; q < 6; ++q) accS = fma(ps[rows[q]], L.B[5 * rows[q] + js], accS);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int i = j + 4 * t, ic = min(i, 14);
+                        const int i = js + 4 * t, ic = min(i, 14);
                         const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
-                        ah = fma(pr[ic], bv, ah);
+                        ahS = fma(ps[ic], bv, ahS);
                     }
-                    ah = quad_sum(ah);
+                    ahS = quad_sum(ahS);
+                    if constexpr (kStoresLast) store_T();
                     if (ln < 60) {
-                        L.S[5 * r + j] = acc;
-                        if (j == 0) L.S[5 * r + 4] = ah;
+                        L.S[5 * rs + js] = accS;
+                        if (js == 0) L.S[5 * rs + 4] = ahS;
                     }
                 }
                 wave_lds_sync();
                 QLN_SWEEP_TICK(tk_blocks);
-                // ---- [Qxx | Qx] = [Hxx | gx] + A'[T | pv] ----
                 {
+                    // ---- [Qxx | Qx] = [Hxx | gx] + A'[T | pv] ----
                     const int c = ln & 15;
                     const double t2 = L.T[2 * kLd + c], t9 = L.T[9 * kLd + c];
                     double qv[4];  // as above: loads of all four passes unconditional (row clamped), stores predicated
@@ -747,59 +755,63 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         acc = fma(ac, tq, acc);
                         qv[it] = acc;
                     }
+                    auto store_Qxx = [&]() {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int r = (ln >> 4) + 4 * it;
-                        if (r < 15) L.Qxx[kLd * r + c] = qv[it];
-                    }
-                }
-                // ---- [Qux | Qu] = [0 | gu] + B'[T | pv]: force rows (ln = 16 j + c), then the h row in quads ----
-                {
-                    const int j = (ln >> 4), c = ln & 15;
-                    int rows[6];
-                    b_rows(j, rows);
-                    double acc = (c == 15) ? L.g[15 + j] : 0.0;
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = (ln >> 4) + 4 * it;
+                            if (r < 15) L.Qxx[kLd * r + c] = qv[it];
+                        }
+                    };
+                    if constexpr (!kStoresLast) store_Qxx();
+                    // ---- [Qux | Qu] = [0 | gu] + B'[T | pv]: force rows (ln = 16 j + c), then the h row in quads ----
+                    const int jf = (ln >> 4);
+                    int rowsf[6];
+                    b_rows(jf, rowsf);
+                    double quf = *((c == 15) ? L.g + 15 + jf : L.A + kAZero);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.T[kLd * rows[q] + c], acc);
-                    L.Qux[kLd * j + c] = acc;
-                }
-                {
-                    const int c = ln >> 2, p = ln & 3;
-                    double ah = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int i = p + 4 * t, ic = min(i, 14);
-                        const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
-                        ah = fma(bv, L.T[kLd * ic + c], ah);
-                    }
-                    ah = quad_sum(ah);
-                    if (p == 0) L.Qux[4 * kLd + c] = ah + ((c == 15) ? L.g[19] : 0.0);
-                }
-                // ---- Quu = Huu + B'S + mu I: the force rows (and, by symmetry, the h row), then (h, h) in a quad ----
-                {   // every lane runs both parts on clamped indices (no divergent branches around the LDS reads); lanes 0-31
-                    // keep the force rows, the quad of lanes 32-35 keeps (h, h)
-                    const int j = (ln >> 3) & 3, c = min(ln & 7, 4);
-                    int rows[6];
-                    b_rows(j, rows);
-                    const double hdj = L.Hd[15 + j], hd19 = L.Hd[19];
-                    double acc = (j == c) ? hdj + mu : 0.0;
-                    if ((j == 1 && c == 3) || (j == 3 && c == 1)) acc += hfc;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) acc = fma(L.B[5 * rows[q] + j], L.S[5 * rows[q] + c], acc);
-                    const int p = ln & 3;
-                    double ah = 0.0;
+                    for (int q = 0; q < 6; ++q) quf = fma(L.B[5 * rowsf[q] + jf], L.T[kLd * rowsf[q] + c], quf);
+                    if constexpr (!kStoresLast) L.Qux[kLd * jf + c] = quf;
+                    const int ch = ln >> 2, p = ln & 3;
+                    double quh = 0.0;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int i = p + 4 * t, ic = min(i, 14);
                         const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
-                        ah = fma(bv, L.S[5 * ic + 4], ah);
+                        quh = fma(bv, L.T[kLd * ic + ch], quh);
                     }
-                    ah = quad_sum(ah);
+                    quh = quad_sum(quh) + *((ch == 15) ? L.g + 19 : L.A + kAZero);
+                    if constexpr (!kStoresLast) {
+                        if (p == 0) L.Qux[4 * kLd + ch] = quh;
+                    }
+                    // ---- Quu = Huu + B'S + mu I: the force rows (and, by symmetry, the h row), then (h, h) in a quad.  Every lane
+                    // runs both parts on clamped indices; lanes 0-31 keep the force rows, the quad of lanes 32-35 keeps (h, h)
+                    const int ju = (ln >> 3) & 3, cu = min(ln & 7, 4);
+                    int rowsu[6];
+                    b_rows(ju, rowsu);
+                    const double hdj = L.Hd[15 + ju], hd19 = L.Hd[19];
+                    double quu = (ju == cu) ? hdj + mu : 0.0;
+                    if ((ju == 1 && cu == 3) || (ju == 3 && cu == 1)) quu += hfc;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) quu = fma(L.B[5 * rowsu[q] + ju], L.S[5 * rowsu[q] + cu], quu);
+                    double ahu = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = p + 4 * t, ic = min(i, 14);
+                        const double bv = L.B[(i < 15) ? 5 * i + 4 : kBZero];
+                        ahu = fma(bv, L.S[5 * ic + 4], ahu);
+                    }
+                    ahu = quad_sum(ahu);
+                    // ---- the stores ----
+                    if constexpr (kStoresLast) {
+                        store_Qxx();
+                        L.Qux[kLd * jf + c] = quf;
+                        if (p == 0) L.Qux[4 * kLd + ch] = quh;
+                    }
                     if (ln < 32 && (ln & 7) < 5) {
-                        L.Quu[5 * j + c] = acc;
-                        if (c == 4) L.Quu[20 + j] = acc;
+                        L.Quu[5 * ju + cu] = quu;
+                        if (cu == 4) L.Quu[20 + ju] = quu;
                     }
-                    if (ln == 32) L.Quu[24] = ah + hd19 + mu + h_prox;  // + the proximal weight on the step length (see SolveParams)
+                    if (ln == 32) L.Quu[24] = ahu + hd19 + mu + h_prox;  // + the proximal weight on the step length (see SolveParams)
                 }
                 wave_lds_sync();
                 QLN_SWEEP_TICK(tk_sweep);
@@ -926,17 +938,20 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         }
                         pv4[it] = 0.5 * (acc + act_);
                     }
+                    auto store_P = [&]() {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int r = (ln >> 4) + 4 * it;
-                        if (r < 15 && cv) L.P[kLd * r + c] = pv4[it];
-                    }
-                }
-                if (ln < 15) {
-                    double acc = L.Qxx[kLd * ln + 15];
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = (ln >> 4) + 4 * it;
+                            if (r < 15 && cv) L.P[kLd * r + c] = pv4[it];
+                        }
+                    };
+                    if constexpr (!kStoresLast) store_P();
+                    const int lv = min(ln, 14);
+                    double pvn = L.Qxx[kLd * lv + 15];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = fma(L.Qux[kLd * i + ln], dff[i], acc);
-                    L.T[kLd * ln + 15] = acc;
+                    for (int i = 0; i < 5; ++i) pvn = fma(L.Qux[kLd * i + lv], dff[i], pvn);
+                    if constexpr (kStoresLast) store_P();
+                    if (ln < 15) L.T[kLd * ln + 15] = pvn;
                 }
                 wave_lds_sync();
                 QLN_SWEEP_TICK(tk_accept);
