@@ -463,10 +463,22 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
     // where a problem's time goes: s_memtime ticks per phase, reported in info[10..14]
     unsigned long long tk_refresh = 0, tk_blocks = 0, tk_sweep = 0, tk_roll = 0, tk_accept = 0, tk0;
 #define QLN_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tk0; tk0 = t_; } while (0)
+#ifdef QLN_ROLL_STAMPS  // tuning build only: info[10..14] = law + u / slots + stores + step / barrier / merit / (unused) of a roll-out knot
+    unsigned long long rl0 = 0;
+#define QLN_ROLL_BEGIN() rl0 = __builtin_amdgcn_s_memtime()
+#define QLN_ROLL_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - rl0; rl0 = t_; } while (0)
+#else
+#define QLN_ROLL_BEGIN() do {} while (0)
+#define QLN_ROLL_TICK(acc) do {} while (0)
+#endif
 #ifdef QLN_SWEEP_STAMPS  // tuning build only: info[10..14] = the five phases of a sweep knot instead of the five phases of an iteration
     unsigned long long sw0 = 0;
 #define QLN_SWEEP_BEGIN() sw0 = __builtin_amdgcn_s_memtime()
 #define QLN_SWEEP_TICK(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - sw0; sw0 = t_; } while (0)
+#define QLN_ITER_TICK(acc) do { tk0 = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(QLN_ROLL_STAMPS)
+#define QLN_SWEEP_BEGIN() do {} while (0)
+#define QLN_SWEEP_TICK(acc) do {} while (0)
 #define QLN_ITER_TICK(acc) do { tk0 = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define QLN_SWEEP_BEGIN() do {} while (0)
@@ -1008,6 +1020,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                 fetch_lam(grp, lr);
                 wave_lds_sync();
                 for (int k = 0; k < N - 1; ++k) {
+                    QLN_ROLL_BEGIN();
                     load_gains(k + 1, Kn);  // a whole knot of arithmetic between the request and the first use
                     const int slot = k % kGroups;
                     if (lane < kAlphas) {
@@ -1019,6 +1032,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             fmac5_row_bcast<i, i == 0>(u, Kr, dx);
                         });
                         u[4] = fmin(fmax(u[4], h_lo), h_hi);
+                        QLN_ROLL_TICK(tk_refresh);
                         double* sl = slots + (slot * kAlphas + a) * 20;
 #pragma unroll
                         for (int i = 0; i < 15; ++i) sl[i] = x[i];
@@ -1034,9 +1048,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             tz[kAlphas * (20 * (k + 1) + i)] = xn[i];
                         }
                     }
+                    QLN_ROLL_TICK(tk_blocks);
 #pragma unroll
                     for (int j = 0; j < 5; ++j) Kr[j] = Kn[j];
                     wave_lds_sync();
+                    QLN_ROLL_TICK(tk_sweep);
                     if (slot == kGroups - 1 || k == N - 2) {  // a batch of knots kb .. k is complete (wave-uniform)
                         const int kb = k - slot, kk = kb + grp;
                         if (grp >= 0 && kk <= k) {
@@ -1055,6 +1071,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                         }
                         fetch_lam(kb + kGroups + grp, lr);
                     }
+                    QLN_ROLL_TICK(tk_roll);
                 }
                 if (lane < kAlphas) {  // the terminal knot: the roll-out lanes hold x_N
                     double u0[5] = {0, 0, 0, 0, 0};
