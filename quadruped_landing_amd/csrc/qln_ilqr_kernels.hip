@@ -333,7 +333,7 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
     QLN_TAKE(A, 300)  // A (15x15, stride 15) then B (15x5)
     t.B = t.A ? t.A + 225 : nullptr;
     QLN_TAKE(T, 15 * kLd)  // [T | pv]
-    QLN_TAKE(Qxx, 15 * kLd)  // [Qxx | Qx]     (P .. Qxx: contiguous, the roll-outs' (x, u) slots)
+    QLN_TAKE(Qxx, 15 * kLd)  // [Qxx | Qx]     (P .. Hd: contiguous, the roll-outs' (x, u) slots)
     QLN_TAKE(S, 5 * kLd)
     t.K = t.S;  // gains of the knot being swept, 5 rows of 16 (S is dead once Quu is formed); all knots: global scratch
     QLN_TAKE(Qux, 5 * kLd)   // [Qux | Qu]
@@ -982,15 +982,18 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
             // ---- forward: one closed-loop roll-out per step length, lane a < 16 tries alpha = 2^-a and keeps its
             //      trajectory in the scratch, so that the accepted one need not be rolled out again.  Only the
             //      state recursion is serial.  A knot's feedback law lies across the sixteen lanes' registers and reaches a
-            //      lane by DPP row broadcast (below); the merit of the trial trajectories is evaluated three knots at a time by
-            //      the three idle lane groups, from (x_k, u_k) the roll-out lanes leave in LDS (the sweep's P, A, T, Qxx are
-            //      free now) -- nothing of a trial trajectory is read back from memory but the accepted one.
+            //      lane by DPP row broadcast (below); the merit of the trial trajectories is evaluated four knots at a time, a
+            //      lane group per knot, from (x_k, u_k) the roll-out lanes leave in LDS (the sweep's matrices are free now) --
+            //      nothing of a trial trajectory is read back from memory but the accepted one.
             double J_try = INFINITY;
             {
-                constexpr int kGroups = kPerTraj - 1;  // helper lane groups: lanes 16-31, 32-47, 48-63
-                static_assert(kGroups >= 1 && kGroups * kAlphas * 20 <= 3 * ((15 * kLd + 1) & ~1) + 300, "the (x, u) slots live in the sweep's P, A, T, Qxx");
+                // merit: a batch of kGroups knots at a time, one lane group per knot -- the roll-out lanes are one of the groups (they
+                // would idle while the others evaluate; a batch of four instead of three is a quarter fewer evaluations)
+                constexpr int kGroups = kPerTraj;
+                static_assert(kGroups >= 1 && kGroups * kAlphas * 20 <= 3 * ((15 * kLd + 1) & ~1) + 300 + 2 * ((5 * kLd + 1) & ~1) + 26 + 20 + 20,
+                              "the (x, u) slots live in the sweep's matrices, P .. Hd (contiguous in carve())");
                 double* const slots = L.P;  // [kGroups][kAlphas][20]
-                const int a = lane & (kAlphas - 1), grp = lane / kAlphas - 1;  // grp = -1: a roll-out lane
+                const int a = lane & (kAlphas - 1), grp = lane / kAlphas;  // lanes 0 .. kAlphas-1 also roll out
                 const double alpha = ldexp(1.0, -a * kAlphaStep);
                 double* __restrict__ tz = traj + a;
                 double x[15], u[5], xn[15];
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     QLN_ROLL_TICK(tk_sweep);
                     if (slot == kGroups - 1 || k == N - 2) {  // a batch of knots kb .. k is complete (wave-uniform)
                         const int kb = k - slot, kk = kb + grp;
-                        if (grp >= 0 && kk <= k) {
+                        if (kk <= k) {
                             const double* sl = slots + (grp * kAlphas + a) * 20;
                             double xs[15], us[5];
 #pragma unroll
