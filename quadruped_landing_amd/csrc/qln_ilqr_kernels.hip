@@ -42,6 +42,8 @@ constexpr size_t kLdsPerCU = 160 * 1024;
 #define QLN_ALPHA_STEP 1
 #endif
 constexpr int kAlphas = QLN_ALPHAS;        // step lengths tried per iteration: alpha_a = 2^(-a kAlphaStep), a = 0 .. kAlphas-1
+                                           // (16 = one DPP row: the roll-outs take the feedback law by row broadcast; only
+                                           // QLN_ALPHA_STEP is still a free knob)
 constexpr int kAlphaStep = QLN_ALPHA_STEP;
 constexpr int kPerTraj = kWave / kAlphas;  // lanes that share the merit evaluation of one trial trajectory
 constexpr int kIneq = 6;       // inequality rows per knot
