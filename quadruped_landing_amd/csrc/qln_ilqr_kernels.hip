@@ -51,11 +51,19 @@ constexpr int kEnt = 88;       // doubles per knot in the step-entry scratch (85
 constexpr int kKn = 9;         // per-knot scalars kept in LDS
 constexpr int kLd = 17;        // leading dimension of the sweep's LDS matrices: 16 columns + 1 (a stride of 16 doubles puts a column in two LDS banks)
 constexpr int kKg = 80;        // doubles per knot of the feedback law in the scratch: 5 rows of [15 gains, feed-forward]
-// Entries of the LDS images of A (15x15, stride 15) and B (15x5) that no step block ever has (step_structure_ok below): they hold
-// 0.0 for the whole sweep.  "value or zero" is then ONE read with a selected address -- hipcc turns a select between a loaded
+// The sweep needs four entries of A = d x+/d x per column c -- the diagonal A(c, c), A(2, c), A(9, c) and the coupling
+// A(c-7, c) (step_structure_ok below) -- in T = P A by column and in Qxx = .. + A'T by row, the same four either way.  Its LDS
+// image is therefore not the 15x15 matrix but the compact table AC[16][4] = {A(c,c), A(2,c) (0 for c = 2), A(9,c) (0 for c = 9),
+// A(c-7,c) (0 where there is no coupling)}: a column's four are two 16-byte reads at one address instead of four reads at four
+// computed ones.  Row 15 and the slots no step block fills hold 0.0 for the whole sweep, as does B(1, 0) of the B image
+// (15x5, behind the table): "value or zero" is then ONE read with a selected address -- hipcc turns a select between a loaded
 // value and a constant into a branch around the load, with a wait of its own, and the reads of a phase stop overlapping.
-constexpr int kAZero = 1;      // A(0, 1)
+constexpr int kAcB = 64;       // offset of the B image behind the table
+constexpr int kAZero = 60;     // AC[15][0]
 constexpr int kBZero = 5;      // B(1, 0)
+__host__ __device__ constexpr int ac_slot(int row, int col) {  // where A(row, col) lies in the table (see above)
+    return 4 * col + (row == col ? 0 : row == 2 ? 1 : row == 9 ? 2 : 3);
+}
 
 // per-knot scalars (lane = knot phase -> backward sweep)
 enum { KN_W = 0, KN_T0 = 1, /* t0..t5 = max(0, lam + rho g); the row is active where t > 0 */ KN_CQ = 7 /* (lb/2) cos(theta) */, KN_ELL = 8 };
@@ -309,7 +317,7 @@ constexpr bool step_structure_ok() {
     return true;
 }
 static_assert(step_structure_ok(), "the sparse products of the Riccati sweep cover every possible non-zero of a step block");
-static_assert(!step_union_present(0, 1) && !step_union_present(1, 15), "the zero slots of the A / B images are outside the union pattern");
+static_assert(!step_union_present(1, 15), "the zero slot of the B image is outside the union pattern");
 
 struct Lds {
     double *X, *U, *K, *leq, *kn, *P, *A, *B, *T, *S, *Qxx, *Qux, *Quu, *g, *Hd;
@@ -332,8 +340,8 @@ __host__ __device__ __forceinline__ Carved carve(double* base, int N) {
     off += (size_t)(((n) + 1) & ~1);
     // the sweep's matrices first (compile-time offsets), row stride 16 -- see the sweep
     QLN_TAKE(P, 15 * kLd)
-    QLN_TAKE(A, 300)  // A (15x15, stride 15) then B (15x5)
-    t.B = t.A ? t.A + 225 : nullptr;
+    QLN_TAKE(A, 300)  // the table AC[16][4] of A's entries, then B (15x5); the rest belongs to the roll-outs' slots
+    t.B = t.A ? t.A + kAcB : nullptr;
     QLN_TAKE(T, 15 * kLd)  // [T | pv]
     QLN_TAKE(Qxx, 15 * kLd)  // [Qxx | Qx]     (P .. Hd: contiguous, the roll-outs' (x, u) slots)
     QLN_TAKE(S, 5 * kLd)
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
 #define JW(row, col, val)                                                                        \
     {                                                                                            \
         constexpr int pos_ = step_union_pos(row, col);                                           \
-        if (lane == (pos_ & 63)) L.map[pos_] = ((col) < 15) ? 15 * (row) + (col) : 225 + 5 * (row) + ((col) - 15); \
+        if (lane == (pos_ & 63)) L.map[pos_] = ((col) < 15) ? ac_slot(row, col) : kAcB + 5 * (row) + ((col) - 15); \
     }
         QLN_STEP_ENTRIES();
 #undef JW
@@ -708,8 +716,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     const bool cv = c < 15;
                     const int cc = cv ? c : 0;
                     const int cq = max(cp, 0);
-                    const double a0 = L.A[16 * cc], a2 = L.A[(c == 2) ? kAZero : 30 + cc], a9 = L.A[(c == 9) ? kAZero : 135 + cc];
-                    const double ac = L.A[(cp >= 0) ? 15 * cq + cc : kAZero];
+                    const double* acp = L.A + 4 * c;  // (row 15 of the table is zero)
+                    const double a0 = acp[0], a2 = acp[1], a9 = acp[2], ac = acp[3];
                     // the four passes are independent: every lane loads (clamped row / column, always inside P) and only the
                     // stores are predicated, so that the LDS reads of all passes are in flight together instead of one
                     // exec-masked pass (and its waits) after the other
@@ -758,8 +766,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int it = 0; it < 4; ++it) {
                         const int r = min((ln >> 4) + 4 * it, 14);
                         const int rp = a_coupling(r), rq = max(rp, 0);
-                        const double a0 = L.A[16 * r], a2 = L.A[(r == 2) ? kAZero : 30 + r], a9 = L.A[(r == 9) ? kAZero : 135 + r];
-                        const double ac = L.A[(rp >= 0) ? 15 * rq + r : kAZero];
+                        const double* arp = L.A + 4 * r;
+                        const double a0 = arp[0], a2 = arp[1], a9 = arp[2], ac = arp[3];
                         const double tr = L.T[kLd * r + c], tq = L.T[kLd * rq + c];
                         double acc = *((c == 15) ? L.g + r : (r == c) ? L.Hd + r : L.A + kAZero);
                         if ((r == 1 && c == 2) || (r == 2 && c == 1)) acc += h12;
