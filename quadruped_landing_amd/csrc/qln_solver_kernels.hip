@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
     // s_l: multipliers of the dynamics rows of knots kc0-1 .. kc0+nk-1 (15 each; knot -1 = zeros)
     // s_g (the chunk's slice of the result, for the coalesced store) lives in s_z's bytes, see k_constraint_jvp:
     // 18.4 KB instead of 28.7 KB of LDS, 8 waves per CU instead of 5
-    __shared__ double s_z[kStageRoom], s_l[15 * (kPC + 1)];
+    // s_b: the 29 multipliers of the initial-state and terminal rows (one lane adds fifteen of them to x_1, one fourteen to x_N)
+    __shared__ double s_z[kStageRoom], s_l[15 * (kPC + 1)], s_b[30];
     static_assert(kStageRoom >= 20 * (kPC + 1), "the result slice fits in the slice of Z it aliases");
     double* const s_g = s_z;
     const int lane = threadIdx.x;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
         const int nk = min(kPC, N - 1 - kc0);
         const int nz = 20 * nk + 15;
         const bool last_chunk = (kc0 + nk == N - 1);
+        double l_ci, l_co, l_bp, l_fc;
         {
             constexpr int kLamIters = (15 * (kPC + 1) + kWave - 1) / kWave;
             double zr[kStageIters], lr[kLamIters];
@@ -187,11 +189,21 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
                 lr[it] = Lb[pv.o_dyn + max(j, 0)];
                 if (j < 0) lr[it] = 0.0;
             }
+            // Every multiplier a lane adds behind the products -- contact, final-control and clearance rows of its knot, the
+            // initial-state / terminal rows -- is requested HERE, with the slices, unconditionally (clamped indices): requested
+            // where it is used, inside the lane's branches, each was a memory round trip of its own at the end of the wave's life.
+            const int kq = min(kc0 + lane, N - 1);
+            l_ci = Lb[pv.o_ci + kq];
+            l_co = Lb[pv.o_co + min(max(kq + 1 - kt, 0), N - kt)];
+            l_bp = Lb[pv.o_bp + kq];
+            l_fc = Lb[pv.o_fc];
+            const double l_b = Lb[min(lane, 28)];
             wave_lds_sync();  // the previous chunk's readers are done
             stage_store(s_z, zr, lane);
 #pragma unroll
             for (int it = 0; it < kLamIters; ++it)
                 if (it * kWave + lane < 15 * (kPC + 1)) s_l[it * kWave + lane] = lr[it];
+            if (lane < 29) s_b[lane] = l_b;
             wave_lds_sync();
         }
         const bool valid = lane < nk;
@@ -224,22 +236,19 @@ __global__ __launch_bounds__(kWave) void k_constraint_vjp(BatchParams P, const d
                 for (int i = 0; i < 15; ++i) gk[i] -= s_l[15 * lane + i];
                 if (kk == 0) {
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) gk[i] += Lb[i];        // I(15) on x_1
+                    for (int i = 0; i < 15; ++i) gk[i] += s_b[i];        // I(15) on x_1
                 }
                 if (kk == N - 1) {
 #pragma unroll
-                    for (int i = 0; i < 14; ++i) gk[i] += Lb[15 + i];   // I(15)[1:14,:] on x_N
+                    for (int i = 0; i < 14; ++i) gk[i] += s_b[15 + i];   // I(15)[1:14,:] on x_N
                 }
-                const double l_ci = Lb[pv.o_ci + kk];
-                const double l_co = (K >= kt) ? Lb[pv.o_co + (K - kt)] : 0.0;
-                gk[4] += pv.init1 ? l_ci : l_co;
-                gk[6] += pv.init1 ? l_co : l_ci;
+                const double l_cok = (K >= kt) ? l_co : 0.0;
+                gk[4] += pv.init1 ? l_ci : l_cok;
+                gk[6] += pv.init1 ? l_cok : l_ci;
                 if (kk == N - 2) {
-                    const double l_fc = Lb[pv.o_fc];
                     gk[16] += l_fc;
                     gk[18] += l_fc;
                 }
-                const double l_bp = Lb[pv.o_bp + kk];
                 gk[1] += l_bp;
                 gk[2] += dth * l_bp;
             }
