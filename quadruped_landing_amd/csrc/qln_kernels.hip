@@ -151,6 +151,27 @@ __device__ __forceinline__ double objective_term(const double* z, const double* 
     return stage ? zz[19] * ((((a + bb) + cc) + dd) + c40) : (a + bb) + c40;
 }
 
+// the same with the record already in registers (D = rec[0..19], d = rec[20..39], c40 = rec[40]): qln_eval_all requests a
+// knot's record with the slice of Z, a memory round trip before it is needed
+__device__ __forceinline__ double objective_term_regs(const double* z, const double (&D)[20], const double (&d)[20], double c40, bool stage) {
+    double zz[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) zz[i] = z[(i < 15 || stage) ? i : 14];
+    double a = (0.5 * (D[0] * zz[0])) * zz[0], bb = d[0] * zz[0];
+#pragma unroll
+    for (int i = 1; i < 15; ++i) {
+        a = a + (0.5 * (D[i] * zz[i])) * zz[i];
+        bb = bb + d[i] * zz[i];
+    }
+    double cc = (0.5 * (D[15] * zz[15])) * zz[15], dd = d[15] * zz[15];
+#pragma unroll
+    for (int i = 16; i < 20; ++i) {
+        cc = cc + (0.5 * (D[i] * zz[i])) * zz[i];
+        dd = dd + d[i] * zz[i];
+    }
+    return stage ? zz[19] * ((((a + bb) + cc) + dd) + c40) : (a + bb) + c40;
+}
+
 // J <- J + term_0 + term_1 + ... in knot order (src/costs.jl:9-15): the wave's terms go through LDS, every lane adds
 // them in the same order (lanes past the last knot hold 0.0, and J + 0.0 == J).
 __device__ __forceinline__ double add_terms_in_order(double J, double term, double* s_term, int lane) {
@@ -233,6 +254,34 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             bnd = P.bnd[(int64_t)b * 30 + min(lane, 29)];  // x0[lane] for lane < 15, xf[lane - 15] after
         }
     }
+    // WITH_F: what the objective and the gradient need of the cost table is requested with the slice -- the lane's knot's record
+    // (eval_f, lane = knot) and the D_j, d_j of the lane's entries of the slice (grad_f!, lane = entry) -- so that they are in
+    // registers when the value phase is over, not a memory round trip after it
+    double oD[WITH_F ? 20 : 1], od[WITH_F ? 20 : 1], oc40 = 0.0, gD[WITH_F ? kStageIters : 1], gd[WITH_F ? kStageIters : 1];
+    auto request_cost = [&](int kc0) {
+        if constexpr (WITH_F) {
+            const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * P.N * 41 : 0);
+            const int nk = min(KC, P.N - 1 - kc0);
+            const bool last = (kc0 + nk == P.N - 1);
+            const double* rec = cost + (int64_t)(kc0 + min(lane, last ? nk : nk - 1)) * 41;
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                oD[i] = rec[i];
+                od[i] = rec[20 + i];
+            }
+            oc40 = rec[40];
+            const int ng = 20 * nk + (last ? 15 : 0);
+#pragma unroll
+            for (int it = 0; it < kStageIters; ++it) {
+                const int e = min(it * kWave + lane, ng - 1);
+                const int kk = e / 20, j = e - 20 * kk;
+                const double* ck = cost + (int64_t)(kc0 + kk) * 41;
+                gD[it] = ck[j];
+                gd[it] = ck[20 + j];
+            }
+        }
+    };
+    request_cost(kc_begin);
     __builtin_amdgcn_sched_barrier(0);
 
     const ProblemDesc pd = P.desc[b];  // one 32-byte scalar load
@@ -297,6 +346,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const double* __restrict__ zsrc = Zb + 20 * kc0;
 #pragma unroll
                 for (int it = 0; it < kStageIters; ++it) zr[it] = zsrc[min(it * kWave + lane, nz - 1)];
+                request_cost(kc0);
             }
             wave_lds_sync();  // the previous chunk's drain reads precede this chunk's staging writes
             // (the tile has room for all kStageIters*64 doubles; what lies past the slice is never read)
@@ -399,7 +449,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             {
                 const bool own = valid || (last_chunk && lane == nk);
                 const int kk = own ? lane : 0;
-                const double term = objective_term(s_z + 20 * kk, cost + (int64_t)(kc0 + kk) * 41, valid);
+                const double term = objective_term_regs(s_z + 20 * kk, oD, od, oc40, valid);
                 J_obj = add_terms_in_order(J_obj, own ? term : 0.0, s_c + KC * 15, lane);
                 if (last_chunk && nk == kWave) {  // wave-uniform
                     const double tn = objective_term(s_z + 20 * nk, cost + (int64_t)(N - 1) * 41, false);
@@ -414,9 +464,8 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
 #pragma unroll
                 for (int it = 0; it < kStageIters; ++it) {
                     const int e = min(it * kWave + lane, ng - 1);
-                    const int kk = e / 20, j = e - 20 * kk;
-                    const double* ck = cost + (int64_t)(kc0 + kk) * 41;
-                    const double lin = ck[j] * s_z[e] + ck[20 + j];
+                    const int kk = e / 20;
+                    const double lin = gD[it] * s_z[e] + gd[it];
                     const double hk = s_z[min(20 * kk + 19, nz - 1)];
                     const double gv = (kk < nk) ? hk * lin : lin;
                     if (it * kWave + lane < ng) Gb[e] = gv;
