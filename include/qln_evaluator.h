@@ -187,9 +187,14 @@ int qln_gauss_newton_step(qln_handle* h, const double* Z, const double* c, doubl
  * states are rolled out from x0); out = the solution: its dynamics / initial-condition rows are zero to the last bit
  * by construction, the remaining rows to options->tol_violation when status = 0.
  * info (device, may be NULL): QLN_SOLVE_INFO_STRIDE doubles per problem {outer iterations, iLQR iterations, objective
- * f of the returned Z, constraint violation (the solver's measure: the rows and bounds it penalises), final penalty
- * rho, status (0 = converged to tol_violation, 1 = iteration limit, 2 = no descent at the largest penalty),
- * augmented cost, last accepted step length, sum of h, LM mu at exit, five phase timers, 1 if the rescue phase ran}.
+ * f of the returned Z (the bits qln_eval_objective gives for it), violation of the returned Z (what
+ * qln_constraint_violation gives for its eval_c!, and solve()'s bounds on theta and quirk Q6's on the knots after the
+ * first), final penalty rho, status (0 = converged to tol_violation, 1 = iteration limit, 2 = no descent at the largest
+ * penalty), augmented cost, last accepted step length, sum of h, LM mu at exit, five phase timers, 1 if the rescue phase
+ * ran}.  f and the violation are measured on the trajectory that is handed back (the RK4 roll-out); status is the solver's
+ * stop test on its own closed-form roll-out of the same controls, which differs from it by rounding (1e-15 per step): with
+ * status = 0 the reported violation can exceed tol_violation by that much.  max_outer = 0 and rescue_outer = 0 make the
+ * call a roll-out-and-report of the given controls (status 1).
  * There is no reference oracle for the iterates (the reference hands its callbacks to Ipopt); the result is judged by
  * this evaluator: qln_eval_constraint + qln_constraint_violation and qln_eval_objective on the returned Z.
  * Needs a cost table.  QLN_ERR_UNSUPPORTED if a problem does not fit the LDS of a CU (N > ~650).  Stream-ordered.
@@ -217,6 +222,13 @@ typedef struct qln_solve_options {
 } qln_solve_options;
 #define QLN_SOLVE_INFO_STRIDE 16
 int qln_solve_default_options(qln_solve_options* opt);
+/* The variable bounds solve() hands to Ipopt (src/moi.jl:51-67), for a caller that keeps Ipopt: x_l / x_u are host
+ * arrays of n_nlp = 20N-5 doubles, -inf / +inf where the reference sets none.  theta in [theta_min, theta_max] at every
+ * knot, h in [h_min, h_max] at every dynamics knot, and -- with q6_bounds != 0, the default -- the two lower bounds of
+ * src/moi.jl:64-65 exactly where the reference puts them: 1-based 22+20(k-1) and 24+20(k-1), i.e. yb_{k+1} >= 0 and
+ * x1_{k+1} >= 0 (quirk Q6; the source comment says "F", the Ipopt header of the shipped run counts 120 such variables,
+ * src/main.ipynb:222).  opt = NULL: the defaults, which are the reference's literals.  Needs no handle and no GPU. */
+int qln_variable_bounds(int32_t N, const qln_solve_options* opt /* NULL = defaults */, double* x_l, double* x_u);
 int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt /* NULL = defaults */, double* info);
 /* the same with HOST pointers (MOI-mode style: Z copied in, solved on the GPU, copied back; synchronous) -- what the
  * Julia veneer calls in place of `solve(Z0, nlp)`.  info (host, may be NULL): [B][QLN_SOLVE_INFO_STRIDE]. */

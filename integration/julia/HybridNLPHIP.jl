@@ -1,10 +1,16 @@
 # HybridNLPHIP.jl -- the reference-side binding: a drop-in MOI.AbstractNLPEvaluator that forwards the
 # callbacks of /root/reference/src/moi.jl:1-33 to libqln_hip.so (C ABI: include/qln_evaluator.h).
 #
-# NOT EXECUTED in this pipeline (no Julia on either box) -- kept free of logic so that review by
-# reading is credible: every method is one ccall.  Usage inside the reference's notebook, after
-# `include("nlp.jl")` etc.:   nlp = HybridNLPHIP(model, obj, init_mode, k_trans, N, xinit, xterm)
-#                              Z_sol, solver = solve(Z0, nlp)            # src/moi.jl:46, unchanged
+# NOT EXECUTED in this pipeline (no Julia on either box) -- kept free of arithmetic so that review by
+# reading is credible: every evaluator method is one ccall.  Usage inside the reference's notebook, after
+# `include("nlp.jl")`, `include("moi.jl")` etc.:
+#     nlp = HybridNLPHIP(model, obj, init_mode, k_trans, N, xinit, xterm)
+#     Z_sol, solver = solve(Z0, nlp, c_tol=1e-3, tol=1e-3)    # dispatches to the method at the END OF THIS FILE
+# The reference's own `solve` is typed `solve(x0, prob::HybridNLP; ...)` (src/moi.jl:46) and HybridNLP is a concrete
+# struct (src/nlp.jl:13), so it cannot take this type; this file therefore adds a second METHOD of the same generic
+# function `solve` for HybridNLPHIP (same keywords, same Ipopt options, same bounds) -- src/moi.jl itself is not edited.
+# tests/test_julia_binding.py holds every ccall and struct of this file to include/qln_evaluator.h (symbol, argument
+# count, pointer / integer / double class of every argument, field order and width of the three structs).
 using LinearAlgebra        # diag
 using MathOptInterface
 const MOI = MathOptInterface
@@ -110,4 +116,37 @@ function solve_hip(x0, prob::HybridNLPHIP; c_tol=1.0e-6)
     qln_check(ccall((:qln_solve_host, LIBQLN), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{QlnSolveOptions}, Ptr{Cdouble}),
                     prob.handle, Z, opt, info))
     return Z, info
+end
+
+# ---- the reference's Ipopt solve, for this evaluator type: a method of `solve` (src/moi.jl:46-103) ------------------------
+# Same generic function, same keyword arguments and defaults, same five things handed to Ipopt.  What differs from the
+# HybridNLP method, on purpose:
+#   * the variable bounds come from the library (qln_variable_bounds: theta, h and the two lower bounds of quirk Q6 at the
+#     reference's own indices 22+20(k-1), 24+20(k-1)) instead of being restated here;
+#   * the evaluator Ipopt calls back is `prob` itself.  The reference's MOI.eval_constraint_jacobian passes the GLOBAL
+#     `nlp` to jac_c! (src/moi.jl:22) and jac_c! reads the GLOBAL `lb` (src/constraints.jl:270,272) -- quirk Q4: both are
+#     sidestepped, the veneer's callbacks use their argument's handle, whose model carries lb.
+# Requires `using Ipopt` in the session, as the reference's notebook has (MathOptInterface 0.9: MOI.SingleVariable).
+function solve(x0, prob::HybridNLPHIP; tol=1.0e-6, c_tol=1.0e-6, max_iter=2000)
+    n_nlp = num_primals(prob)
+    length(x0) == n_nlp || error("solve: x0 has $(length(x0)) entries, the problem has $n_nlp variables")
+    x_l = Vector{Float64}(undef, n_nlp); x_u = Vector{Float64}(undef, n_nlp)
+    qln_check(ccall((:qln_variable_bounds, LIBQLN), Cint, (Int32, Ptr{QlnSolveOptions}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    prob.N, C_NULL, x_l, x_u))
+    block = MOI.NLPBlockData(MOI.NLPBoundsPair.(prob.lb, prob.ub), prob, true)       # true: has an objective
+    solver = Ipopt.Optimizer()
+    for (name, value) in ("max_iter" => max_iter, "tol" => tol, "constr_viol_tol" => c_tol)
+        solver.options[name] = value
+    end
+    x = MOI.add_variables(solver, n_nlp)
+    for (xi, lo, hi, start) in zip(x, x_l, x_u, x0)
+        v = MOI.SingleVariable(xi)
+        MOI.add_constraint(solver, v, MOI.LessThan(hi))        # +-Inf bounds included, as the reference adds them
+        MOI.add_constraint(solver, v, MOI.GreaterThan(lo))
+        MOI.set(solver, MOI.VariablePrimalStart(), xi, start)
+    end
+    MOI.set(solver, MOI.NLPBlock(), block)
+    MOI.set(solver, MOI.ObjectiveSense(), MOI.MIN_SENSE)
+    MOI.optimize!(solver)
+    return MOI.get(solver, MOI.VariablePrimal(), x), solver
 end

@@ -139,6 +139,7 @@ SIGNATURES = {
     "qln_eval_friction_cone": (C.c_int, [_vp, _dp, C.c_double, _dp, _dp]),
     "qln_constraint_violation": (C.c_int, [_vp, _dp, _dp]),
     "qln_solve_default_options": (C.c_int, [C.POINTER(QlnSolveOptions)]),
+    "qln_variable_bounds": (C.c_int, [C.c_int32, C.POINTER(QlnSolveOptions), _dp, _dp]),
     "qln_solve": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_solve_host": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),

@@ -627,6 +627,32 @@ int qln_solve_default_options(qln_solve_options* o) {
     return QLN_OK;
 }
 
+int qln_variable_bounds(int32_t N, const qln_solve_options* opt, double* x_l, double* x_u) {
+    if (N < 2) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_variable_bounds: N must be >= 2");
+    if (!x_l || !x_u) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_variable_bounds: null output");
+    qln_solve_options o;
+    qln_solve_default_options(&o);
+    if (opt) o = *opt;
+    const int64_t n_nlp = 20 * (int64_t)N - 5;
+    for (int64_t i = 0; i < n_nlp; ++i) {
+        x_l[i] = -HUGE_VAL;
+        x_u[i] = HUGE_VAL;
+    }
+    for (int32_t k = 0; k < N; ++k) {  // 0-based knot; the reference's indices are 1-based, k = 1..N
+        x_l[20 * k + 2] = o.theta_min;  // src/moi.jl:55-56
+        x_u[20 * k + 2] = o.theta_max;
+        if (k < N - 1) {
+            x_l[20 * k + 19] = o.h_min;  // src/moi.jl:59-60
+            x_u[20 * k + 19] = o.h_max;
+            if (o.q6_bounds) {           // src/moi.jl:64-65: 22+20(k-1), 24+20(k-1) 1-based = yb_{k+1}, x1_{k+1} (quirk Q6)
+                x_l[20 * k + 21] = 0.0;
+                x_l[20 * k + 23] = 0.0;
+            }
+        }
+    }
+    return QLN_OK;
+}
+
 int qln_solve(qln_handle* h, double* Z, const qln_solve_options* opt, double* info) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = check_cost(h)) return rc;

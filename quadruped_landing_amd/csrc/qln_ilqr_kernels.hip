@@ -1205,28 +1205,88 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
 // (the iterations above roll out in closed form, 1e-15 away), so that initial-condition, dynamics and contact rows of the
 // returned Z are zero to the last bit when the evaluator looks at them.  One thread per problem; a kernel of its own so
 // that the solver kernel's register allocation is not disturbed (with this loop inside it the sweep ran 27 % slower).
-__global__ __launch_bounds__(kWave) void k_exact_rollout(BatchParams P, double* __restrict__ Zio) {
+// The report is restated on THAT trajectory: info[2] = eval_f of the returned Z in the reference's operation order
+// (src/costs.jl:6-16: the same bits qln_eval_objective gives), info[3] = the violation of the returned Z -- the rows of
+// eval_c! the roll-out does not zero by construction (terminal, final-control, clearance with the reference's kinked
+// |sin|, src/constraints.jl:98-113,150,154; contact rows, which only an infeasible x0 can violate) as
+// qln_constraint_violation measures them, and solve()'s variable bounds on theta and quirk Q6's two (src/moi.jl:54-65) on
+// the knots after the first.  status (info[5]) stays the solver's verdict on its own closed-form roll-out.
+__global__ __launch_bounds__(kWave) void k_exact_rollout(BatchParams P, SolveParams S, double* __restrict__ Zio, double* __restrict__ info) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     const ProblemDesc pd = P.desc[b];
+    const int N = P.N, kt = pd.k_trans, im = pd.init_mode;
     const double Ib = P.mb * (P.lb * P.lb) / 12;
     double* __restrict__ Zb = Zio + (int64_t)b * P.z_stride;
     const double* __restrict__ x0g = P.bnd + (int64_t)b * 30;
+    const double* __restrict__ costg = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
     double x[15], u[5], xn[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
         x[i] = x0g[i];
         Zb[i] = x[i];
     }
-    for (int k = 0; k < P.N - 1; ++k) {
+    double f = 0.0, viol = 0.0, poison = 0.0;
+    auto up = [&](double v) {  // max that does not swallow a NaN (fmax would): a non-finite row poisons the report
+        viol = fmax(viol, v);
+        poison += 0.0 * v;
+    };
+    // rows of one knot's state: contact (the foot of init_mode at every knot, the other from k_trans on), clearance, bounds
+    auto state_rows = [&](int k, const double (&x)[15]) {
+        const double y_init = (im == 1) ? x[4] : x[6], y_other = (im == 1) ? x[6] : x[4];
+        up(fabs(y_init));
+        if (k + 1 >= kt) up(fabs(y_other));
+        up(-(x[1] - (P.lb / 2) * fabs(sin(x[2]))));
+        if (k >= 1) {
+            up(fmax(x[2] - S.th_hi, S.th_lo - x[2]));
+            if (S.q6) up(fmax(-x[1], -x[3]));
+        }
+    };
+    for (int k = 0; k < N - 1; ++k) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) u[j] = Zb[20 * k + 15 + j];
-        step_forward(P, k, pd.k_trans, pd.init_mode, Ib, x, u, xn);
+        {   // h_k * stagecost(obj[k], x_k, u_k), added in knot order
+            const double* __restrict__ rec = costg + 41 * k;
+            double a = (0.5 * (rec[0] * x[0])) * x[0], bb = rec[20] * x[0];
+#pragma unroll
+            for (int i = 1; i < 15; ++i) {
+                a = a + (0.5 * (rec[i] * x[i])) * x[i];
+                bb = bb + rec[20 + i] * x[i];
+            }
+            double cc = (0.5 * (rec[15] * u[0])) * u[0], dd = rec[35] * u[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) {
+                cc = cc + (0.5 * (rec[15 + j] * u[j])) * u[j];
+                dd = dd + rec[35 + j] * u[j];
+            }
+            f = f + u[4] * ((((a + bb) + cc) + dd) + rec[40]);
+        }
+        state_rows(k, x);
+        if (k == N - 2) up(fabs(u[1] + u[3] + P.mb * P.g));
+        step_forward(P, k, kt, im, Ib, x, u, xn);
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
             x[i] = xn[i];
             Zb[20 * (k + 1) + i] = xn[i];
         }
+    }
+    {   // termcost(obj[N], x_N) and the terminal rows
+        const double* __restrict__ rec = costg + 41 * (N - 1);
+        double a = (0.5 * (rec[0] * x[0])) * x[0], bb = rec[20] * x[0];
+#pragma unroll
+        for (int i = 1; i < 15; ++i) {
+            a = a + (0.5 * (rec[i] * x[i])) * x[i];
+            bb = bb + rec[20 + i] * x[i];
+        }
+        f = f + ((a + bb) + rec[40]);
+        state_rows(N - 1, x);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) up(fabs(x[i] - x0g[15 + i]));
+    }
+    if (poison != poison) viol = poison;
+    if (info) {
+        info[16 * (int64_t)b + 2] = f;
+        info[16 * (int64_t)b + 3] = viol;
     }
 }
 
@@ -1249,7 +1309,7 @@ hipError_t launch_al_ilqr(const BatchParams& p, const SolveParams& s, double* Z,
         return hipGetLastError();
     };
     if (hipError_t e2 = two_per_simd ? go(k_al_ilqr<2>) : go(k_al_ilqr<1>); e2 != hipSuccess) return e2;
-    hipLaunchKernelGGL(k_exact_rollout, dim3((p.B + kWave - 1) / kWave), dim3(kWave), 0, stream, p, Z);
+    hipLaunchKernelGGL(k_exact_rollout, dim3((p.B + kWave - 1) / kWave), dim3(kWave), 0, stream, p, s, Z, info);
     return hipGetLastError();
 }
 

@@ -246,3 +246,136 @@ def test_both_register_budgets_of_the_solver_kernel_give_the_same_bits():
         out.append((Z.view(nb, -1)[:1024].clone(), info[:1024, :10].clone()))
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+# ---- the solver against what the reference HOLDS: its six solved trajectories (src/data_{1..6}.csv) ----------------------
+def _reference_trajectory_problem(golden_dir, i):
+    """The notebook problem (N = 61, k_trans = 21, init_mode 1, xf = xterm, the notebook's cost) with x0 taken from the
+    file's first 15 entries (data_1..5 are consistent with that problem; their cost weights at solve time are
+    unknown, so they pin feasibility only -- data_6 is the notebook's own run: x0 = xinit to 1.7e-9 and its cost IS known)."""
+    import os
+    from quadruped_landing_amd import problem_gen as PG
+
+    Zf = np.loadtxt(os.path.join(golden_dir, f"data_{i}.csv"))
+    nb = PG.notebook_problem()
+    if i != 6:
+        nb.x0[0] = Zf[:15]
+    nb.Z = Zf[None, :].copy()
+    return nb, Zf
+
+
+def _knots(Z):
+    return np.concatenate([np.asarray(Z).reshape(-1)[:1215], np.zeros(5)]).reshape(61, 20)
+
+
+def test_rollout_and_report_of_the_reference_runs_controls(golden_dir):
+    """What the reference's data CAN pin of the solver kernel: its roll-out, its objective and its violation measure.
+    qln_solve with max_outer = 0 / rescue_outer = 0 rolls the CONTROLS of src/data_6.csv out from xinit (RK4, the
+    evaluator's step) and reports.  The file's states satisfy the dynamics rows to 1.49e-6 (KA2), so the roll-out must
+    retrace the file to that order -- 1.7e-6 (the CPU oracle gives the same figure) -- its objective must be KA1's
+    1.1608112892558562e+02 to 3e-8 relative, and its violation stays under the reference run's own 1.4928675395736724e-06
+    (src/main.ipynb:710-712).  The reported f / violation are the evaluator's, bit for bit / to the last ulp of sin()."""
+    import torch
+    from quadruped_landing_amd import HybridNLP
+
+    nb, Zf = _reference_trajectory_problem(golden_dir, 6)
+    nlp = HybridNLP(nb.model, nb.obj, nb.init_mode, nb.k_trans, nb.N, nb.x0, nb.xf)
+    Z, info = nlp.solve(nlp.upload_Z(nb.Z), max_outer=0, rescue_outer=0)
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()[0]
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    X, Xf = _knots(Zh[0]), _knots(Zf)
+    drift = np.abs(X[:, :15] - Xf[:, :15]).max()
+    print(f"roll-out of data_6.csv's controls: max distance from the file's states {drift:.3e}; f = {f[0]:.10f} "
+          f"(KA1 116.0811289256), violation {viol[0]:.3e} (reference run 1.493e-06); solver's report f {inf[2]:.10f} viol {inf[3]:.3e}")
+    assert inf[0] == 0 and inf[1] == 0 and inf[5] == 1            # nothing iterated
+    assert np.array_equal(X[:60, 15:], Xf[:60, 15:])               # the controls are the file's (h inside its bounds)
+    assert drift <= 2e-6
+    assert abs(f[0] - 1.1608112892558562e02) <= 3e-8 * 1.1608112892558562e02
+    assert viol[0] <= 1.4928675395736724e-06
+    assert inf[2] == f[0]                                          # reported objective = the evaluator's bits
+    assert abs(inf[3] - max(viol[0], bviol[0])) <= 1e-15           # reported violation = the evaluator's (+ bounds)
+    ci = nlp.cinds(0)
+    for grp in (0, 2, 3, 4):                                       # rows the roll-out satisfies by construction
+        assert np.all(c[ci[grp][0] - 1: ci[grp][1]] == 0.0), grp
+
+
+def test_warm_start_from_the_reference_runs_own_solution(golden_dir):
+    """qln_solve started from the controls of src/data_6.csv -- the point the reference's Ipopt run ENDED at, objective
+    1.1608112892558562e+02, violation 1.4928675395736724e-06, exit "Restoration Failed" (src/main.ipynb:707-727): a point
+    Ipopt gave up at, not a stationary point -- on the notebook problem with the notebook cost.  Required: status 0, a
+    violation no larger than the reference run's, an objective no larger than the reference run's, bounds kept.
+    What happens (printed): the solver does not stay there.  It walks to the same landing it finds from the notebook's
+    initial guess Z0 -- f = 112.1812 from either start (they agree to 3e-6) -- which is 1.14 away from the file in the
+    states (m, rad, m/s), 83 N in the forces and 3.2 ms in the step lengths; that distance is asserted as measured so that
+    a change of behaviour shows.  So the file pins the solver's roll-out / objective / violation (test above) and an upper
+    bound on the objective of a feasible point; the iterates remain unpinned -- the reference holds nothing for them."""
+    import torch
+    from quadruped_landing_amd import HybridNLP
+
+    nb, Zf = _reference_trajectory_problem(golden_dir, 6)
+    nlp = HybridNLP(nb.model, nb.obj, nb.init_mode, nb.k_trans, nb.N, nb.x0, nb.xf)
+    f_file = float(nlp.eval_f(nlp.upload_Z(nb.Z)).cpu()[0])
+    assert f_file == 1.1608112892558562e02                      # KA1, through the HIP path, at the starting point
+    Z, info = nlp.solve(nlp.upload_Z(nb.Z))
+    Z0sol, info0 = nlp.solve(nlp.initial_guess())
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()[0]
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    f0 = float(nlp.eval_f(Z0sol).cpu()[0])
+    X, Xf, X0 = _knots(Zh[0]), _knots(Zf), _knots(Z0sol.cpu().numpy())
+    d_state = np.abs(X[:, :14] - Xf[:, :14]).max()
+    d_force = np.abs(X[:60, 15:19] - Xf[:60, 15:19]).max()
+    d_h = np.abs(X[:60, 19] - Xf[:60, 19]).max()
+    d_z0 = np.abs(X[:, :14] - X0[:, :14]).max()
+    print(f"warm start from data_6.csv: outer {inf[0]:.0f}, iLQR iterations {inf[1]:.0f}, status {inf[5]:.0f}; evaluator: "
+          f"f = {f[0]:.7f} (file: {f_file:.7f}; from Z0: {f0:.7f}), violation {viol[0]:.3e} (file: 1.493e-06), bound violation "
+          f"{bviol[0]:.1e}; distance from the file: states {d_state:.3e}, forces {d_force:.3e} N, step lengths {d_h:.3e} s; "
+          f"distance from the solution found from Z0: states {d_z0:.3e}")
+    assert inf[5] == 0
+    assert viol[0] <= 1.4928675395736724e-06
+    assert bviol[0] <= 1e-6
+    assert f[0] <= 1.1608112892558562e02 + 1e-6
+    assert abs(f[0] - f0) <= 1e-4 and d_z0 <= 5e-3              # the same landing as from Z0
+    assert d_state <= 1.5 and d_force <= 100.0 and d_h <= 5e-3  # as measured (1.14, 83 N, 3.2 ms): it leaves the file's
+    ci = nlp.cinds(0)
+    for grp in (0, 2, 3, 4):
+        assert np.all(c[ci[grp][0] - 1: ci[grp][1]] == 0.0), grp
+
+
+@pytest.mark.parametrize("i", [1, 2, 3, 4, 5])
+def test_warm_start_from_the_references_other_trajectories_feasibility_only(golden_dir, i):
+    """src/data_{1..5}.csv: also N = 61 landings, consistent with k_trans = 21 / init_mode 1 when x0 is the file's first
+    state.  Their Q / R / dt at solve time are unknown, so the OBJECTIVE is not comparable (the notebook's
+    cost is used, and said so); what they pin is feasibility, in two steps: (i) the evaluator finds the file feasible to
+    the reference's tolerance (<= 5e-6 on every row -- except, for data_1 and data_2, the final-control row
+    F1y + F2y + mb g = 0, which those two files violate by 22.7 / 2.27 N: they predate that constraint); (ii) the roll-out
+    of the file's controls retraces the file (<= 4e-4: data_3's dynamics residual accumulated over 60 steps); (iii) started
+    from the file's controls the solver returns status 0 and a violation <= 1e-6, judged by the evaluator."""
+    import torch
+    from quadruped_landing_amd import HybridNLP
+
+    nb, Zf = _reference_trajectory_problem(golden_dir, i)
+    nlp = HybridNLP(nb.model, nb.obj, nb.init_mode, nb.k_trans, nb.N, nb.x0, nb.xf)
+    c0 = nlp.eval_c(nlp.upload_Z(nb.Z)).cpu().numpy()
+    ci = nlp.cinds(0)
+    rows = np.ones(c0.size, dtype=bool)
+    if i in (1, 2):
+        rows[ci[5][0] - 1] = False                                 # the final-control row (see above)
+    eq = np.abs(c0[: ci[5][1]])[rows[: ci[5][1]]].max()
+    v0 = max(eq, np.maximum(-c0[ci[6][0] - 1:], 0).max())
+    Zr, _ = nlp.solve(nlp.upload_Z(nb.Z), max_outer=0, rescue_outer=0)
+    drift = np.abs(_knots(Zr.cpu().numpy())[:, :15] - _knots(Zf)[:, :15]).max()
+    Z, info = nlp.solve(nlp.upload_Z(nb.Z))
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()[0]
+    viol, f, bviol, c, Zh = _judge(nlp, Z)
+    d_state = np.abs(_knots(Zh[0])[:, :14] - _knots(Zf)[:, :14]).max()
+    print(f"data_{i}.csv: file violation {v0:.3e}" + (f" (final-control row {abs(c0[ci[5][0] - 1]):.3g} left out)" if i in (1, 2) else "")
+          + f", roll-out of its controls within {drift:.3e} of it; solve: status {inf[5]:.0f}, iLQR iterations {inf[1]:.0f}, "
+          f"violation {viol[0]:.3e}, bound violation {bviol[0]:.1e}, f (notebook cost, not the file's) {f[0]:.4f}, max state "
+          f"distance from the file {d_state:.3e}")
+    assert v0 <= 5e-6
+    assert drift <= 4e-4
+    assert inf[5] == 0 and viol[0] <= 1e-6 * 1.0001 and bviol[0] <= 1e-6
+    assert np.all(np.isfinite(Zh))
