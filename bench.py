@@ -7,13 +7,22 @@ inputs and outputs resident in HBM.  Default workload = BASELINE.json configs[2]
 k_trans=14, FP64 -- "config 3" of BASELINE.md): the HBM-bound regime the metric's roofline half is quoted on;
 configs[1] (B=1024, launch-latency regime) is timed beside it and reported under "other".  The --workload names
 config2/config3/config4 follow BASELINE.md's 1-based table, i.e. configs[1]/[2]/[3].
-Multi-GPU: weak scaling, one process per GPU (the driver's torch.distributed.run line), the shard is generated
-locally, no data-path collective; one RCCL gather of the per-problem results (objective f, constraint violation) to
-rank 0 after the K steps, inside the timed region ("gather f, c (or norms)"), driven through the C ABI
-(qln_comm_*, include/qln_multi.h) -- torch.distributed (gloo) only carries RCCL's 128-byte id from rank 0 to the
-others.  The gather of the full constraint vectors (379 MB per rank) is timed once outside the region and reported as
-`gather_c_ms`; Jacobian values stay resident on the GPU that produced them.  `--gpus N` WITHOUT a launcher drives all
-N devices from this one process through qln_multi_* (same partitioning, same gather).
+
+ONE measurement for every N.  Whatever N is and however the N GPUs are driven, the line is produced the same way:
+  * every GPU owns a full-size shard (weak scaling), generated ON that GPU by the same device-side generator with the
+    shard's index as the seed (the ragged workload: host generator, uploaded); no data-path collective;
+  * `value` = knot evals of all GPUs / the wall clock of the K-launch region, which is bracketed by a barrier +
+    device synchronisation on both sides and contains NOTHING but the K launches of every GPU (max over ranks);
+  * the end-of-job tail -- objective + constraint violation of every problem, then the single gather of those
+    per-problem results to GPU 0 (north_star: "an RCCL gather over xGMI only at the end") -- runs right after the timed
+    region and is reported beside it as `gather_ms`, for N = 1 too (where the gather degenerates to a device copy);
+    the gather of the full constraint vectors (379 MB per rank) is timed once more as `gather_c_ms`; Jacobian values
+    stay resident on the GPU that produced them;
+  * `roofline` is computed from the SLOWEST GPU's HIP-event launch average (per-GPU averages are listed beside it).
+Two drivers produce that line: 'ranks' = one process per GPU (the driver's torch.distributed.run line; also plain
+`python bench.py` at N = 1), RCCL through qln_comm_* -- torch.distributed (gloo) only carries RCCL's 128-byte id;
+'single-process' = this process drives all N devices through qln_multi_* (one host thread per device issues its
+launches).  `config.driver`, `config.workload_data` and `config.timing` say which produced the line.
 """
 import argparse
 import json
@@ -271,52 +280,95 @@ def roofline_record(args, batch, ms_each):
                            "frac": strict_achieved / HBM_PEAK_GBS}}
 
 
+def tail_note():
+    return ("value = knot evals / wall clock of the K-launch region only (barrier + device sync on both sides); the end-of-job "
+            "tail (eval_f + constraint violation + gather of the per-problem results to GPU 0) follows it and is reported as "
+            "gather_ms -- the same for every N and both drivers")
+
+
 def run_single_process(args):
     """--mode single-process: this process drives all N devices through include/qln_multi.h (one handle, stream and
-    buffer set per device; launches issued to every device before anything is waited for; one RCCL gather of the
-    per-problem objective and constraint violation to device 0 at the end, inside the timed region)."""
+    buffer set per device; one host thread per device issues its launches; one RCCL gather of the per-problem objective
+    and constraint violation to device 0 at the end).  Same workload generator, same timed region, same tail as
+    run_ranks: the two drivers' lines are comparable with each other and across N."""
     import torch
-    from quadruped_landing_amd import multi, problem_gen as PG
+    from quadruped_landing_amd import PlanarQuadruped, multi, problem_gen as PG
 
     n = args.gpus
     if torch.cuda.device_count() < n:
         raise SystemExit(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible")
     w = WORKLOADS[args.workload]
-    shards = [PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=r, ragged=w["ragged"], build_obj=False) for r in range(n)]
-    cat = lambda name: np.concatenate([getattr(b, name) for b in shards])
-    m = multi.MultiNLP(shards[0].model, None, cat("init_mode"), cat("k_trans"), w["N"], cat("x0"), cat("xf"),
-                       devices=list(range(n)), jac_format=args.jac_format)
-    m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=w["ragged"])
-    m.set_Z(cat("Z"))
+    B, N = w["B"], w["N"]
+    device_data = not (w["ragged"] or args.host_data)
+    model = PlanarQuadruped()
+    if device_data:
+        kt = np.full(B * n, w["k_trans"], dtype=np.int32)
+        im = np.full(B * n, 1, dtype=np.int32)
+        xf = np.tile(PG.terminal_state(model), (B * n, 1))
+        m = multi.MultiNLP(model, None, im, kt, N, np.zeros((B * n, 15)), xf, devices=list(range(n)), jac_format=args.jac_format)
+        m.sample_drop_states([PG.drop_state_sampler(r, model) for r in range(n)])  # shard r = rank r's workload (seed r)
+        m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=False)
+        m.initial_guess()
+        m.perturb_point([PG.drop_state_sampler(r, model, stream_offset=4 * B) for r in range(n)], sigma=0.05)
+        shard0 = PG.LandingBatch(model, N, kt[:B], im[:B], np.zeros((B, 15)), xf[:B], None, None)  # (sizes only: x0 lives on the device)
+        data_how = "generated on the device (qln_sample_drop_states / qln_set_lqr_cost / qln_initial_guess / qln_perturb_point), seed = shard index"
+    else:
+        shards = [PG.make_batch(B, N, w["k_trans"] or 14, 1, seed=r, ragged=w["ragged"], build_obj=False) for r in range(n)]
+        cat = lambda name: np.concatenate([getattr(b, name) for b in shards])
+        m = multi.MultiNLP(model, None, cat("init_mode"), cat("k_trans"), N, cat("x0"), cat("xf"),
+                           devices=list(range(n)), jac_format=args.jac_format)
+        m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=w["ragged"])
+        m.set_Z(cat("Z"))
+        shard0 = shards[0]
+        data_how = "host generator (problem_gen.make_batch), uploaded; seed = shard index"
     m.synchronize()
     m.alloc_vals(placed=args.placement_trials > 1)
     K, W = args.steps, args.warmup
     what = multi.GATHER_F | multi.GATHER_VIOL
-    m.time_c_and_jac(0, max(W, 1))  # warm-up launches, and one gather so that RCCL is initialised
+    m.time_c_and_jac(0, max(W, 1))  # warm-up launches, and one tail so that RCCL is initialised
     m.eval_f()
     m.constraint_violation()
     m.gather(what)
     m.synchronize()
-    t0 = time.perf_counter()
-    ms_dev = m.time_c_and_jac(0, K)  # K launches per device, all devices concurrently; returns with the devices idle
+    # ---- the timed region: K launches per device, nothing else.  qln_multi_time_* synchronises every device, releases
+    # one issue thread per device together and returns when all devices are idle; its own host clock brackets exactly that.
+    ms_dev, wall_ms = m.time_c_and_jac(0, K)
+    elapsed = wall_ms * 1e-3
+    # ---- the end-of-job tail
     tg = time.perf_counter()
     m.eval_f()
     m.constraint_violation()
     m.gather(what)                   # the single end-of-job exchange (RCCL over xGMI)
     m.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    total_B = w["B"] * n
-    out = base_record(args, total_B * w["N"] * K / elapsed, n, elapsed, w["B"], w["N"], m.z_stride,
-                      {"driver": "one process, qln_multi_* (include/qln_multi.h)",
-                       "jacobian_buffer": "qln_vals_alloc_placed per device" if args.placement_trials > 1 else "plain allocation"})
-    out["roofline"] = roofline_record(args, shards[0], ms_dev[:1] / K)
-    out["roofline"]["launch_ms_avg_per_device"] = [float(x) / K for x in ms_dev]
-    out["gather_ms"] = (t1 - tg) * 1e3
+    t_gather = time.perf_counter() - tg
+    m.gather(multi.GATHER_C)         # for the record: the full (ragged) constraint vectors to device 0
+    m.synchronize()
+    tg = time.perf_counter()
+    m.gather(multi.GATHER_C)
+    m.synchronize()
+    t_gather_c = time.perf_counter() - tg
+    total_B = B * n
+    out = base_record(args, total_B * N * K / elapsed, n, elapsed, B, N, m.z_stride,
+                      {"driver": "one process, one issue thread per device, qln_multi_* (include/qln_multi.h)",
+                       "jacobian_buffer": "qln_vals_alloc_placed per device" if args.placement_trials > 1 else "plain allocation",
+                       "workload_data": data_how, "timing": tail_note(),
+                       "multi_gpu_status": multi_gpu_status(n)})
+    per_dev = [float(x) / K for x in ms_dev]
+    out["roofline"] = roofline_record(args, shard0, np.array([max(per_dev)]))
+    out["roofline"]["launch_ms_avg_per_device"] = per_dev
+    out["roofline"]["launch_ms_source"] = "HIP events on each device's stream around its K launches; the slowest device is the one priced"
+    out["gather_ms"] = t_gather * 1e3
+    out["gather_c_ms"] = t_gather_c * 1e3
     f, viol, _ = m.gathered()
     assert f.shape == (total_B,) and np.all(np.isfinite(f)) and np.all(np.isfinite(viol))
     m.close()
     return out
+
+
+def multi_gpu_status(n):
+    return ("single GPU" if n == 1 else
+            f"N = {n}: this code path had never executed with more than one device before this run (the build pool exposes one "
+            "GPU per box; shard bookkeeping is CPU-tested, the one-shard clique GPU-tested)")
 
 
 class _GlooComm:
@@ -413,52 +465,64 @@ def run_ranks(args):
         if comm is not None:
             comm.barrier()
 
+    def gather1(t):
+        """the end-of-job gather of one per-problem array to rank 0; with one rank and no communicator it degenerates to
+        the device copy a one-rank gather is"""
+        if comm is not None:
+            return comm.gather(t)[0]
+        return t.clone()
+
     # warmup (untimed): W launches, one objective pass, and one gather so RCCL's channels exist
     nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=max(W, 1))
     nlp.eval_f(Z, f)
     nlp.constraint_violation(c, viol)
-    if comm is not None:
-        comm.gather(f)
-        comm.gather(viol)
+    gather1(f)
+    gather1(viol)
     barrier()
 
+    # ---- the timed region: K launches, nothing else, bracketed by barrier + device synchronisation on both sides
     t0 = time.perf_counter()
     ms_each = nlp.time_c_and_jac(Z, c, vals, warmup=0, iters=K)  # K launches, HIP events around each
-    t_gather = 0.0
-    if comm is not None:
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        nlp.eval_f(Z, f)
-        nlp.constraint_violation(c, viol)
-        f_all, _ = comm.gather(f)        # the single end-of-job exchange (RCCL over xGMI): per-problem results
-        viol_all, _ = comm.gather(viol)
-        torch.cuda.synchronize()
-        t_gather = time.perf_counter() - tg
     barrier()
     elapsed = time.perf_counter() - t0
+    # ---- the end-of-job tail (the same for every N): per-problem results, then the single gather to rank 0
+    tg = time.perf_counter()
+    nlp.eval_f(Z, f)
+    nlp.constraint_violation(c, viol)
+    f_all = gather1(f)               # RCCL over xGMI when there is more than one rank
+    viol_all = gather1(viol)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - tg
+    barrier()
+    gather1(c)                       # for the record: the full (ragged) constraint vectors to rank 0
+    barrier()
+    tg = time.perf_counter()
+    gather1(c)
+    torch.cuda.synchronize()
+    t_gather_c = time.perf_counter() - tg
+    launch_avg = float(np.mean(ms_each))
+    launch_avgs = [launch_avg]
     if comm is not None:
         elapsed = comm.max(elapsed)
         t_gather = comm.max(t_gather)
-    t_gather_c = 0.0
-    if comm is not None:  # for the record, outside the timed region: the full (ragged) constraint vectors to rank 0
-        comm.gather(c)
-        barrier()
-        tg = time.perf_counter()
-        comm.gather(c)
-        torch.cuda.synchronize()
-        t_gather_c = comm.max(time.perf_counter() - tg)
+        t_gather_c = comm.max(t_gather_c)
+        slowest = comm.max(launch_avg)   # the roofline prices the slowest GPU's launches
+        launch_avgs = [launch_avg] if world == 1 else [launch_avg, slowest]
 
     out = None
     if rank == 0:
         out = base_record(args, batch.B * batch.N * world * K / elapsed, world, elapsed, batch.B, batch.N, nlp.z_stride,
-                          {"driver": "one process per GPU" + ("" if comm is None else ", RCCL through qln_comm_* (include/qln_multi.h)" if rccl_error is None
+                          {"driver": "one process per GPU" + (", no communicator (one rank: the gather is a device copy)" if comm is None
+                                                          else ", RCCL through qln_comm_* (include/qln_multi.h)" if rccl_error is None
                                                           else f", RCCL UNAVAILABLE ({rccl_error}): end-of-job gather over gloo (host memory)"),
-                           "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms, "workload_data": data_how})
-        out["roofline"] = roofline_record(args, batch, ms_each)
-        if comm is not None:
-            assert f_all.numel() == batch.B * world and viol_all.numel() == batch.B * world
-            out["gather_ms"] = t_gather * 1e3        # f + constraint violation, inside the timed region
-            out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank), outside it
+                           "jacobian_buffer": placement_how, "placement_trials_ms": placement_ms, "workload_data": data_how + ", seed = rank",
+                           "timing": tail_note(), "multi_gpu_status": multi_gpu_status(world)})
+        out["roofline"] = roofline_record(args, batch, ms_each if len(launch_avgs) == 1 else np.array([launch_avgs[1]]))
+        out["roofline"]["launch_ms_source"] = ("HIP events around each of the K launches on the rank's stream; rank 0's average"
+                                               + ("" if len(launch_avgs) == 1 else f" {launch_avgs[0]:.4f} ms, slowest rank's {launch_avgs[1]:.4f} ms (priced)"))
+        assert f_all.numel() == batch.B * world and viol_all.numel() == batch.B * world
+        out["gather_ms"] = t_gather * 1e3        # eval_f + constraint violation + their gather: the end-of-job tail, after the timed region
+        out["gather_c_ms"] = t_gather_c * 1e3    # full c (c_total doubles per rank)
         if world == 1 and not args.no_other:
             # all four callbacks of an NLP iteration from one read of Z in one launch (qln_eval_all): same workload, same buffers
             gg = nlp.new_Z()

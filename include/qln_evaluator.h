@@ -122,6 +122,10 @@ const char* qln_version(void);
 /* Lifetime.  `device` is a HIP device ordinal. */
 int qln_create(const qln_batch_desc* desc, int device, qln_handle** out);
 int qln_destroy(qln_handle* h);
+/* What qln_create will lay out for `desc`, without a device: the sizes and the per-problem offsets (exclusive scans of
+ * m_nlp(b) / nnz(b) rounded up to desc->align; src/nlp.jl:48-87 per problem).  Host arithmetic only -- the same code
+ * qln_create runs first; desc->x0 / xf / cost are not read.  c_off, j_off: [B] or NULL. */
+int qln_layout(const qln_batch_desc* desc, qln_dims* dims, int64_t* c_off, int64_t* j_off);
 /* All launches go to `hip_stream` (a hipStream_t; NULL = the default stream). */
 int qln_set_stream(qln_handle* h, void* hip_stream);
 int qln_synchronize(qln_handle* h);

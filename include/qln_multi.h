@@ -72,6 +72,23 @@ int qln_comm_barrier(qln_comm* comm);
 /* ------------------------------------------------------------------ one process, n devices */
 typedef struct qln_multi qln_multi;
 
+/* Where everything of shard r lies -- the host bookkeeping of qln_multi_create, which needs no device: contiguous balanced
+ * ranges (qln_shard_range), the cuts of the batch's host arrays, and the shard's place in the gathered constraint vector
+ * (shards are ragged: a shard's constraint buffer holds sum_b round_up(18N - k_trans(b) + 16, align) doubles).
+ * qln_multi_create / qln_multi_set_Z / qln_multi_gather work from exactly this plan. */
+typedef struct qln_shard_plan {
+    int64_t b_begin, b_end;  /* problems [b_begin, b_end) of the batch                                              */
+    int64_t z_begin;         /* doubles: the shard's first row in the batch's host Z / grad = b_begin * z_stride      */
+    int64_t cost_begin;      /* doubles into desc->cost: b_begin * N * 41 for a per-problem table, 0 for a shared one */
+    int32_t cost_batch;      /* 1 (shared table) or the shard's problem count                                       */
+    int32_t reserved;
+    int64_t c_displ;         /* where the shard's constraint vector starts in the gathered one                      */
+    int64_t z_total, c_total, j_total; /* buffer sizes of the shard's evaluator handle (doubles)                     */
+} qln_shard_plan;
+/* plan: [n_devices]; c_off: [B] or NULL, global problem b's offset in the GATHERED constraint vector; c_total (may be
+ * NULL): its length.  Host arithmetic only: works without a GPU. */
+int qln_multi_plan(const qln_batch_desc* desc, int n_devices, qln_shard_plan* plan, int64_t* c_off, int64_t* c_total);
+
 /* Shards the batch described by `desc` (all of it in host memory, as for qln_create) over `n_devices` HIP devices
  * (`devices` = their ordinals, NULL = 0 .. n_devices-1), creates one evaluator handle + stream + buffer set per
  * device and the RCCL clique.  A per-problem cost table (cost_batch == B) is sharded like the problems. */
@@ -85,7 +102,8 @@ int qln_multi_shard(const qln_multi* m, int r, int* device, int64_t* b_begin, in
                     double** Z, double** c, double** vals, double** f, double** viol);
 /* global problem b's offset in the GATHERED constraint vector (shard-local c_off + the shard's displacement) */
 int qln_multi_get_offsets(const qln_multi* m, int64_t* c_off /*[B]*/, int64_t* c_total);
-/* Z of the whole batch from host memory ([B][z_stride] doubles as for qln_eval_*_host), cut and copied to the shards */
+/* Z of the whole batch from host memory ([B][z_stride] doubles as for qln_eval_*_host), cut and copied to the shards.
+ * Returns when the copies are complete: Z_host may be freed or reused as soon as the call returns. */
 int qln_multi_set_Z(qln_multi* m, const double* Z_host);
 /* or built where it is used: the notebook's initial guess on every device (qln_initial_guess) */
 int qln_multi_initial_guess(qln_multi* m);
@@ -112,9 +130,13 @@ int qln_multi_gather(qln_multi* m, uint32_t what, int root_shard);
 /* the gathered arrays, copied to host memory after waiting for the gather: f, viol: [B]; c: [c_total] (see
  * qln_multi_get_offsets).  Pointers may be NULL. */
 int qln_multi_gathered_to_host(qln_multi* m, double* f, double* viol, double* c);
-/* Measurement helper for bench.py: K back-to-back fused launches on every device, HIP events per device around the
- * whole run; ms_per_device[r] = elapsed ms of shard r's K launches.  Returns after all devices are idle. */
-int qln_multi_time_constraint_and_jacobian(qln_multi* m, int32_t warmup, int32_t iters, float* ms_per_device);
+/* Measurement helper for bench.py: `iters` back-to-back fused launches on every device, issued by ONE HOST THREAD PER
+ * DEVICE that are released together, so that every device's queue starts within microseconds of the others (issuing all
+ * of device 0's launches, then all of device 1's ... from one thread would start device r about r * iters launch
+ * overheads late and book host issue order as lost scaling).  ms_per_device[r]: HIP events on shard r's stream around
+ * its `iters` launches (events are created before, destroyed after the timed region).  wall_ms (may be NULL): host clock
+ * from the release of the threads until every device is idle.  Returns after all devices are idle. */
+int qln_multi_time_constraint_and_jacobian(qln_multi* m, int32_t warmup, int32_t iters, float* ms_per_device, double* wall_ms);
 
 #ifdef __cplusplus
 }

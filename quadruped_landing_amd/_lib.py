@@ -115,6 +115,7 @@ SIGNATURES = {
     "qln_version": (C.c_char_p, []),
     "qln_create": (C.c_int, [C.POINTER(QlnBatchDesc), C.c_int, C.POINTER(_vp)]),
     "qln_destroy": (C.c_int, [_vp]),
+    "qln_layout": (C.c_int, [C.POINTER(QlnBatchDesc), C.POINTER(QlnDims), _i64p, _i64p]),
     "qln_set_stream": (C.c_int, [_vp, _vp]),
     "qln_synchronize": (C.c_int, [_vp]),
     "qln_get_dims": (C.c_int, [_vp, C.POINTER(QlnDims)]),

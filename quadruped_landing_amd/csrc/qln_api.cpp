@@ -169,30 +169,72 @@ const char* qln_last_error(void) { return g_err.c_str(); }
 int qln_set_last_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 const char* qln_version(void) { return "quadruped_landing_amd 0.1 (gfx950)"; }
 
+// Argument checks and the layout of a batch (sizes, per-problem offsets): everything qln_create decides before it touches
+// a device.  c_off / j_off: [B] or null.
+static int layout_of(const qln_batch_desc* d, const char* who, bool need_states, qln_dims* D, int64_t* c_off, int64_t* j_off) {
+    const std::string w = std::string(who) + ": ";
+    if (d->B < 1) return fail(QLN_ERR_INVALID_ARGUMENT, w + "B must be >= 1");
+    if (d->N < 2) return fail(QLN_ERR_INVALID_ARGUMENT, w + "N must be >= 2");
+    if (d->N > 50000000 / 20) return fail(QLN_ERR_INVALID_ARGUMENT, w + "N too large for 32-bit indices");
+    if (!d->k_trans || !d->init_mode || (need_states && (!d->x0 || !d->xf)))
+        return fail(QLN_ERR_INVALID_ARGUMENT, w + "null descriptor array");
+    if (d->cost_batch != 1 && d->cost_batch != d->B)
+        return fail(QLN_ERR_INVALID_ARGUMENT, w + "cost_batch must be 1 or B");
+    const int32_t n_nlp = 20 * d->N - 5;
+    const int64_t z_stride = d->z_stride ? d->z_stride : n_nlp;
+    if (z_stride < n_nlp) return fail(QLN_ERR_INVALID_ARGUMENT, w + "z_stride < n_nlp");
+    const int64_t align = d->align ? d->align : 16;
+    if (align < 1) return fail(QLN_ERR_INVALID_ARGUMENT, w + "align must be >= 1");
+    const int32_t fmt = d->jac_format;
+    if (fmt != QLN_JAC_FORMAT_DENSE_BLOCKS && fmt != QLN_JAC_FORMAT_STRUCTURAL)
+        return fail(QLN_ERR_INVALID_ARGUMENT, w + "unknown jac_format");
+    for (int32_t b = 0; b < d->B; ++b) {
+        if (d->k_trans[b] < 1 || d->k_trans[b] > d->N + 1)
+            return fail(QLN_ERR_INVALID_ARGUMENT, w + "k_trans out of range [1, N+1] at problem " + std::to_string(b));
+        if (d->init_mode[b] != 1 && d->init_mode[b] != 2)
+            return fail(QLN_ERR_INVALID_ARGUMENT, w + "init_mode must be 1 or 2 at problem " + std::to_string(b));
+    }
+    const int64_t jalign = (align % 2) ? align * 2 : align;  // keep j_off even: 16-byte stores
+    int64_t co = 0, jo = 0;
+    int32_t m_max = 0, nnz_max = 0, dyn_max = 0;
+    for (int32_t b = 0; b < d->B; ++b) {
+        const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b], fmt);
+        dyn_max = std::max(dyn_max, nnz_dyn_of(d->N, d->k_trans[b], fmt));
+        co = round_up(co, align);
+        jo = round_up(jo, jalign);
+        if (c_off) c_off[b] = co;
+        if (j_off) j_off[b] = jo;
+        co += m;   // no padding behind the last problem: for B == 1 the totals are exactly m_nlp / nnz,
+        jo += nz;  // so Ipopt-owned buffers of the reference's sizes can be passed as they are
+        m_max = std::max(m_max, m);
+        nnz_max = std::max(nnz_max, nz);
+    }
+    D->B = d->B;
+    D->N = d->N;
+    D->n_nlp = n_nlp;
+    D->m_nlp_max = m_max;
+    D->nnz_max = nnz_max;
+    D->nnz_dynamic = dyn_max;
+    D->z_stride = z_stride;
+    D->z_total = z_stride * (int64_t)d->B;
+    D->c_total = co;
+    D->j_total = jo;
+    return QLN_OK;
+}
+
+int qln_layout(const qln_batch_desc* d, qln_dims* dims, int64_t* c_off, int64_t* j_off) {
+    if (!d || !dims) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_layout: null argument");
+    return layout_of(d, "qln_layout", false, dims, c_off, j_off);
+}
+
 int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     if (!d || !out) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: null argument");
     *out = nullptr;
-    if (d->B < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: B must be >= 1");
-    if (d->N < 2) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N must be >= 2");
-    if (d->N > 50000000 / 20) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: N too large for 32-bit indices");
-    if (!d->k_trans || !d->init_mode || !d->x0 || !d->xf)
-        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: null descriptor array");
-    if (d->cost_batch != 1 && d->cost_batch != d->B)
-        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: cost_batch must be 1 or B");
-    const int32_t n_nlp = 20 * d->N - 5;
-    const int64_t z_stride = d->z_stride ? d->z_stride : n_nlp;
-    if (z_stride < n_nlp) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: z_stride < n_nlp");
-    int64_t align = d->align ? d->align : 16;
-    if (align < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: align must be >= 1");
+    qln_dims lay{};
+    std::vector<int64_t> c_off((size_t)std::max(d->B, 0)), j_off((size_t)std::max(d->B, 0));
+    if (int rc = layout_of(d, "qln_create", true, &lay, c_off.data(), j_off.data())) return rc;
+    const int64_t z_stride = lay.z_stride;
     const int32_t fmt = d->jac_format;
-    if (fmt != QLN_JAC_FORMAT_DENSE_BLOCKS && fmt != QLN_JAC_FORMAT_STRUCTURAL)
-        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: unknown jac_format");
-    for (int32_t b = 0; b < d->B; ++b) {
-        if (d->k_trans[b] < 1 || d->k_trans[b] > d->N + 1)
-            return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: k_trans out of range [1, N+1] at problem " + std::to_string(b));
-        if (d->init_mode[b] != 1 && d->init_mode[b] != 2)
-            return fail(QLN_ERR_INVALID_ARGUMENT, "qln_create: init_mode must be 1 or 2 at problem " + std::to_string(b));
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(QLN_ERR_NO_DEVICE, "qln_create: no HIP device visible (this library has no CPU fallback)");
@@ -204,34 +246,10 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     h->model = d->model;
     h->k_trans.assign(d->k_trans, d->k_trans + d->B);
     h->init_mode.assign(d->init_mode, d->init_mode + d->B);
-    h->c_off.resize(d->B);
-    h->j_off.resize(d->B);
-    const int64_t jalign = (align % 2) ? align * 2 : align;  // keep j_off even: 16-byte stores
-    int64_t co = 0, jo = 0;
-    int32_t m_max = 0, nnz_max = 0, dyn_max = 0;
-    for (int32_t b = 0; b < d->B; ++b) {
-        const int32_t m = m_nlp_of(d->N, d->k_trans[b]), nz = nnz_of(d->N, d->k_trans[b], fmt);
-        dyn_max = std::max(dyn_max, nnz_dyn_of(d->N, d->k_trans[b], fmt));
-        co = round_up(co, align);
-        jo = round_up(jo, jalign);
-        h->c_off[b] = co;
-        h->j_off[b] = jo;
-        co += m;   // no padding behind the last problem: for B == 1 the totals are exactly m_nlp / nnz,
-        jo += nz;  // so Ipopt-owned buffers of the reference's sizes can be passed as they are
-        m_max = std::max(m_max, m);
-        nnz_max = std::max(nnz_max, nz);
-    }
+    h->c_off = std::move(c_off);
+    h->j_off = std::move(j_off);
+    h->dims = lay;
     qln_dims& D = h->dims;
-    D.B = d->B;
-    D.N = d->N;
-    D.n_nlp = n_nlp;
-    D.m_nlp_max = m_max;
-    D.nnz_max = nnz_max;
-    D.nnz_dynamic = dyn_max;
-    D.z_stride = z_stride;
-    D.z_total = z_stride * (int64_t)d->B;
-    D.c_total = co;
-    D.j_total = jo;
 
     int rc = QLN_OK;
     auto bail = [&](int code) {

@@ -8,7 +8,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,6 +57,7 @@ struct qln_multi {
         double *Z = nullptr, *c = nullptr, *vals = nullptr, *f = nullptr, *viol = nullptr, *sinfo = nullptr;
         bool vals_placed = false;
         int64_t c_displ = 0;  // where the shard's constraint vector starts in the gathered one
+        int64_t z_begin = 0;  // where the shard's rows start in the batch's host Z (doubles)
     };
     std::vector<Shard> shards;
     std::vector<ncclComm_t> comms;
@@ -218,6 +222,49 @@ int qln_multi_destroy(qln_multi* m) {
     return rc;
 }
 
+// the descriptor of shard [lo, hi): the batch's host arrays cut at problem lo
+static qln_batch_desc shard_desc(const qln_batch_desc& d, const qln_shard_plan& p) {
+    qln_batch_desc sd = d;
+    sd.B = (int32_t)(p.b_end - p.b_begin);
+    sd.k_trans = d.k_trans + p.b_begin;
+    sd.init_mode = d.init_mode + p.b_begin;
+    sd.x0 = d.x0 ? d.x0 + p.b_begin * QLN_NX : nullptr;
+    sd.xf = d.xf ? d.xf + p.b_begin * QLN_NX : nullptr;
+    sd.cost = d.cost ? d.cost + p.cost_begin : nullptr;
+    sd.cost_batch = p.cost_batch;
+    return sd;
+}
+
+int qln_multi_plan(const qln_batch_desc* d, int n, qln_shard_plan* plan, int64_t* c_off, int64_t* c_total) {
+    if (!d || !plan) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_plan: null argument");
+    if (n < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_plan: n_devices must be >= 1");
+    if (d->B < n) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_plan: fewer problems than devices");
+    if (!d->k_trans || !d->init_mode) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_plan: null descriptor array");
+    if (d->cost_batch != 1 && d->cost_batch != d->B) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_plan: cost_batch must be 1 or B");
+    int64_t displ = 0;
+    std::vector<int64_t> local;
+    for (int r = 0; r < n; ++r) {
+        qln_shard_plan& p = plan[r];
+        p = qln_shard_plan{};
+        QM_OK(qln_shard_range(d->B, r, n, &p.b_begin, &p.b_end));
+        const bool per_problem = d->cost_batch == d->B && d->B > 1;
+        p.cost_begin = per_problem ? p.b_begin * (int64_t)d->N * QLN_COST_STRIDE : 0;
+        p.cost_batch = per_problem ? (int32_t)(p.b_end - p.b_begin) : 1;
+        const qln_batch_desc sd = shard_desc(*d, p);
+        qln_dims dims{};
+        local.assign((size_t)sd.B, 0);
+        QM_OK(qln_layout(&sd, &dims, local.data(), nullptr));  // the offsets the shard's own handle will use
+        p.z_begin = p.b_begin * dims.z_stride;
+        p.c_displ = displ;
+        p.z_total = dims.z_total, p.c_total = dims.c_total, p.j_total = dims.j_total;
+        if (c_off)
+            for (int64_t b = 0; b < sd.B; ++b) c_off[p.b_begin + b] = displ + local[(size_t)b];
+        displ += dims.c_total;
+    }
+    if (c_total) *c_total = displ;
+    return QLN_OK;
+}
+
 int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_multi** out) {
     if (!d || !out) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: null argument");
     *out = nullptr;
@@ -245,25 +292,23 @@ int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_mul
         qln_multi_destroy(m);
         return fail(code, keep);
     };
+    std::vector<qln_shard_plan> plan((size_t)n);
+    if (int rc = qln_multi_plan(d, n, plan.data(), m->c_off.data(), &m->c_total)) return bail(rc);
     for (int r = 0; r < n; ++r) {
         auto& s = m->shards[(size_t)r];
+        const qln_shard_plan& p = plan[(size_t)r];
         s.device = devs[(size_t)r];
-        qln_shard_range(d->B, r, n, &s.lo, &s.hi);
-        qln_batch_desc sd = *d;
-        sd.B = (int32_t)(s.hi - s.lo);
-        sd.k_trans = d->k_trans + s.lo;
-        sd.init_mode = d->init_mode + s.lo;
-        sd.x0 = d->x0 + s.lo * QLN_NX;
-        sd.xf = d->xf + s.lo * QLN_NX;
-        if (d->cost && d->cost_batch == d->B) {
-            sd.cost = d->cost + s.lo * (int64_t)d->N * QLN_COST_STRIDE;
-            sd.cost_batch = sd.B;
-        }
+        s.lo = p.b_begin, s.hi = p.b_end;
+        s.c_displ = p.c_displ;
+        s.z_begin = p.z_begin;
+        const qln_batch_desc sd = shard_desc(*d, p);
         if (int rc = qln_create(&sd, s.device, &s.h)) return bail(rc);
         if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)
             return bail(fail(QLN_ERR_HIP, "qln_multi_create: stream creation failed"));
         if (int rc = qln_set_stream(s.h, s.stream)) return bail(rc);
         if (int rc = qln_get_dims(s.h, &s.dims)) return bail(rc);
+        if (s.dims.z_total != p.z_total || s.dims.c_total != p.c_total || s.dims.j_total != p.j_total)
+            return bail(fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: the shard handle's layout differs from the plan"));
         struct {
             double** p;
             int64_t n;
@@ -273,12 +318,6 @@ int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_mul
                 hipMemsetAsync(*b.p, 0, (size_t)std::max<int64_t>(b.n, 1) * 8, s.stream) != hipSuccess)
                 return bail(fail(QLN_ERR_HIP, "qln_multi_create: device buffer allocation failed"));
         }
-        // offsets of the shard's problems in the gathered constraint vector
-        std::vector<int64_t> co((size_t)sd.B);
-        if (int rc = qln_get_offsets(s.h, co.data(), nullptr)) return bail(rc);
-        s.c_displ = m->c_total;
-        for (int64_t b = 0; b < sd.B; ++b) m->c_off[(size_t)(s.lo + b)] = s.c_displ + co[(size_t)b];
-        m->c_total += s.dims.c_total;
         m->z_stride = s.dims.z_stride;
     }
     m->comms.assign((size_t)n, nullptr);
@@ -323,7 +362,13 @@ int qln_multi_set_Z(qln_multi* m, const double* Z_host) {
     if (!m || !Z_host) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_set_Z: null argument");
     for (auto& s : m->shards) {
         QM_HIP(hipSetDevice(s.device));
-        QM_HIP(hipMemcpyAsync(s.Z, Z_host + s.lo * m->z_stride, (size_t)s.dims.z_total * 8, hipMemcpyHostToDevice, s.stream));
+        QM_HIP(hipMemcpyAsync(s.Z, Z_host + s.z_begin, (size_t)s.dims.z_total * 8, hipMemcpyHostToDevice, s.stream));
+    }
+    // the copies read the caller's (pageable) buffer: it must not be freed or reused before they are done, and a C or
+    // Julia caller cannot know when that is -- so the call waits (a one-off upload, never on a timed path)
+    for (auto& s : m->shards) {
+        QM_HIP(hipSetDevice(s.device));
+        QM_HIP(hipStreamSynchronize(s.stream));
     }
     return QLN_OK;
 }
@@ -459,33 +504,57 @@ int qln_multi_gathered_to_host(qln_multi* m, double* f, double* viol, double* c)
     return QLN_OK;
 }
 
-int qln_multi_time_constraint_and_jacobian(qln_multi* m, int32_t warmup, int32_t iters, float* ms_per_device) {
+int qln_multi_time_constraint_and_jacobian(qln_multi* m, int32_t warmup, int32_t iters, float* ms_per_device, double* wall_ms) {
     if (!m || !ms_per_device || iters < 1 || warmup < 0) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_time_constraint_and_jacobian: bad argument");
     const size_t n = m->shards.size();
+    for (auto& s : m->shards)
+        if (!s.vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_time_constraint_and_jacobian: call qln_multi_alloc_vals first");
     std::vector<hipEvent_t> e0(n, nullptr), e1(n, nullptr);
     int rc = QLN_OK;
-    auto launch_all = [&](int times, bool timed) {
-        for (size_t r = 0; r < n && rc == QLN_OK; ++r) {
-            auto& s = m->shards[r];
-            if (!s.vals) {
-                rc = fail(QLN_ERR_INVALID_ARGUMENT, "call qln_multi_alloc_vals first");
-                break;
-            }
-            if (hipSetDevice(s.device) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipSetDevice failed");
-            if (timed && rc == QLN_OK && hipEventRecord(e0[r], s.stream) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventRecord failed");
-            for (int i = 0; i < times && rc == QLN_OK; ++i) rc = qln_eval_constraint_and_jacobian(s.h, s.Z, s.c, s.vals, 0);
-            if (timed && rc == QLN_OK && hipEventRecord(e1[r], s.stream) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventRecord failed");
-        }
-    };
     for (size_t r = 0; r < n && rc == QLN_OK; ++r)
         if (hipSetDevice(m->shards[r].device) != hipSuccess || hipEventCreate(&e0[r]) != hipSuccess || hipEventCreate(&e1[r]) != hipSuccess)
             rc = fail(QLN_ERR_HIP, "hipEventCreate failed");
-    if (rc == QLN_OK && warmup) launch_all(warmup, false);
+    // One host thread per device.  Each binds its device, waits at the gate, then issues its shard's launches and waits
+    // for its device: every device's queue starts within microseconds of the others', whatever `iters` is.  The error
+    // slot of the evaluator is thread-local: a failing thread hands its code and message back.
+    std::vector<int> trc(n, QLN_OK);
+    std::vector<std::string> tmsg(n);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    auto worker = [&](size_t r, int times, bool timed) {
+        auto& s = m->shards[r];
+        int my = QLN_OK;
+        if (hipSetDevice(s.device) != hipSuccess) my = fail(QLN_ERR_HIP, "hipSetDevice failed");
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (timed && my == QLN_OK && hipEventRecord(e0[r], s.stream) != hipSuccess) my = fail(QLN_ERR_HIP, "hipEventRecord failed");
+        for (int i = 0; i < times && my == QLN_OK; ++i) my = qln_eval_constraint_and_jacobian(s.h, s.Z, s.c, s.vals, 0);
+        if (timed && my == QLN_OK && hipEventRecord(e1[r], s.stream) != hipSuccess) my = fail(QLN_ERR_HIP, "hipEventRecord failed");
+        if (my == QLN_OK && hipStreamSynchronize(s.stream) != hipSuccess) my = fail(QLN_ERR_HIP, "hipStreamSynchronize failed");
+        trc[r] = my;
+        if (my != QLN_OK) tmsg[r] = qln_last_error();
+    };
+    auto run_all = [&](int times, bool timed, double* elapsed_ms) {
+        ready = 0;
+        go = false;
+        std::vector<std::thread> th;
+        th.reserve(n);
+        for (size_t r = 0; r < n; ++r) th.emplace_back(worker, r, times, timed);
+        while (ready.load() < (int)n) std::this_thread::yield();
+        const auto t0 = std::chrono::steady_clock::now();
+        go.store(true, std::memory_order_release);
+        for (auto& t : th) t.join();
+        if (elapsed_ms) *elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (size_t r = 0; r < n; ++r)
+            if (trc[r] != QLN_OK) return fail(trc[r], tmsg[r]);
+        return (int)QLN_OK;
+    };
     if (rc == QLN_OK) rc = qln_multi_synchronize(m);
-    if (rc == QLN_OK) launch_all(iters, true);
-    if (rc == QLN_OK) rc = qln_multi_synchronize(m);
+    if (rc == QLN_OK && warmup) rc = run_all(warmup, false, nullptr);
+    if (rc == QLN_OK) rc = run_all(iters, true, wall_ms);
     for (size_t r = 0; r < n && rc == QLN_OK; ++r)
-        if (hipEventElapsedTime(&ms_per_device[r], e0[r], e1[r]) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
+        if (hipSetDevice(m->shards[r].device) != hipSuccess || hipEventElapsedTime(&ms_per_device[r], e0[r], e1[r]) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
     for (size_t r = 0; r < n; ++r) {
         if (e0[r]) (void)hipEventDestroy(e0[r]);
         if (e1[r]) (void)hipEventDestroy(e1[r]);

@@ -61,15 +61,26 @@ def gather_to_root(t, dst: int = 0, group=None) -> Optional[list]:
             return out
         dist.gather(t, gather_list=None, dst=_global(dst, group), group=group)
         return None
+    if min(sizes) == 0:
+        # A rank with an empty shard must still take part: under the nccl backend communicators (and their P2P channels)
+        # are created lazily inside the first collective / batch, and a rank that sits the exchange out leaves its peers'
+        # initialisation waiting.  So with an empty shard anywhere, every rank joins ONE equal-size gather of its data
+        # padded to the longest shard, and the root cuts the padding off (an edge case: the copy does not matter).
+        n = max(sizes)
+        padded = t if t.numel() == n else torch.cat([t, torch.zeros(n - t.numel(), dtype=t.dtype, device=t.device)])
+        if rank == dst:
+            out = [torch.empty_like(padded) for _ in range(world)]
+            dist.gather(padded, gather_list=out, dst=_global(dst, group), group=group)
+            return [o[: sizes[r]] for r, o in enumerate(out)]
+        dist.gather(padded, gather_list=None, dst=_global(dst, group), group=group)
+        return None
     if rank == dst:
         out = [t if r == dst else torch.empty(sizes[r], dtype=t.dtype, device=t.device) for r in range(world)]
-        ops = [dist.P2POp(dist.irecv, out[r], _global(r, group), group) for r in range(world) if r != dst and sizes[r] > 0]
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, out[r], _global(r, group), group) for r in range(world) if r != dst]):
             w.wait()
         return out
-    if t.numel() > 0:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, _global(dst, group), group)]):
-            w.wait()
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, _global(dst, group), group)]):
+        w.wait()
     return None
 
 

@@ -55,8 +55,34 @@ SIGNATURES = {
     "qln_multi_synchronize": (C.c_int, [_vp]),
     "qln_multi_gather": (C.c_int, [_vp, C.c_uint32, C.c_int]),
     "qln_multi_gathered_to_host": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "qln_multi_time_constraint_and_jacobian": (C.c_int, [_vp, C.c_int32, C.c_int32, _fp]),
+    "qln_multi_time_constraint_and_jacobian": (C.c_int, [_vp, C.c_int32, C.c_int32, _fp, C.POINTER(C.c_double)]),
+    "qln_multi_plan": (C.c_int, [C.POINTER(_lib.QlnBatchDesc), C.c_int, _vp, _i64p, _i64p]),
 }
+
+
+class QlnShardPlan(C.Structure):
+    _fields_ = [
+        ("b_begin", C.c_int64),
+        ("b_end", C.c_int64),
+        ("z_begin", C.c_int64),
+        ("cost_begin", C.c_int64),
+        ("cost_batch", C.c_int32),
+        ("reserved", C.c_int32),
+        ("c_displ", C.c_int64),
+        ("z_total", C.c_int64),
+        ("c_total", C.c_int64),
+        ("j_total", C.c_int64),
+    ]
+
+
+def plan(desc, n_devices: int):
+    """qln_multi_plan: (list of per-shard dicts, c_off [B], c_total) -- the host bookkeeping of the multi-GPU layer; needs
+    no GPU.  `desc` is a _lib.QlnBatchDesc describing the whole batch."""
+    plans = (QlnShardPlan * n_devices)()
+    c_off = np.zeros(desc.B, dtype=np.int64)
+    tot = C.c_int64()
+    _lib.check(lib().qln_multi_plan(C.byref(desc), n_devices, C.cast(plans, _vp), c_off.ctypes.data_as(_i64p), C.byref(tot)))
+    return [{f: getattr(p, f) for f, _ in QlnShardPlan._fields_ if f != "reserved"} for p in plans], c_off, tot.value
 
 _mlib = None
 
@@ -209,8 +235,20 @@ class MultiNLP:
     def set_Z(self, Z_host):
         Z = np.zeros((self.B, self.z_stride))
         Z[:, : self.n_nlp] = np.asarray(Z_host, dtype=np.float64).reshape(self.B, -1)[:, : self.n_nlp]
-        self._Z_keep = Z  # the copies are asynchronous
-        _lib.check(lib().qln_multi_set_Z(self._h, Z.ctypes.data))
+        _lib.check(lib().qln_multi_set_Z(self._h, Z.ctypes.data))  # returns when the copies are complete
+
+    def sample_drop_states(self, samplers):
+        """qln_sample_drop_states on every shard's handle (`samplers`: one qln_drop_state_sampler per shard): the synthetic
+        drop states generated where they are used, as the one-process-per-GPU driver does with its rank's sampler."""
+        for r, smp in enumerate(samplers):
+            _lib.check(_lib.lib().qln_sample_drop_states(self.shard(r)["handle"], C.byref(smp)))
+
+    def perturb_point(self, samplers, sigma: float = 0.05, h_min: float = 0.001, h_max: float = 0.02, redraw_h: bool = False):
+        """qln_perturb_point on every shard's Z (after initial_guess)."""
+        for r, smp in enumerate(samplers):
+            sh = self.shard(r)
+            _lib.check(_lib.lib().qln_perturb_point(sh["handle"], C.byref(smp), sh["Z"], float(sigma), float(h_min), float(h_max),
+                                                    int(redraw_h)))
 
     def initial_guess(self):
         _lib.check(lib().qln_multi_initial_guess(self._h))
@@ -257,9 +295,12 @@ class MultiNLP:
         return out
 
     def time_c_and_jac(self, warmup: int, iters: int):
+        """(ms per device from HIP events around its `iters` launches, host wall ms from the common release of the per-device
+        issue threads until every device is idle)"""
         ms = (C.c_float * self.n_devices)()
-        _lib.check(lib().qln_multi_time_constraint_and_jacobian(self._h, warmup, iters, ms))
-        return np.array(ms[:], dtype=np.float64)
+        wall = C.c_double()
+        _lib.check(lib().qln_multi_time_constraint_and_jacobian(self._h, warmup, iters, ms, C.byref(wall)))
+        return np.array(ms[:], dtype=np.float64), wall.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -167,3 +167,40 @@ def test_bench_fallback_comm_over_gloo():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _empty_shard_worker(rank, world, port, q, empty_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 0 if rank == empty_rank else 5 + 3 * rank
+        t = torch.arange(n, dtype=torch.float64) + 100.0 * rank
+        out = D.gather_to_root(t)
+        if rank == 0:
+            ok = len(out) == world
+            for r in range(world):
+                want = torch.arange(0 if r == empty_rank else 5 + 3 * r, dtype=torch.float64) + 100.0 * r
+                ok = ok and torch.equal(out[r], want)
+            q.put(bool(ok))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("empty_rank", [0, 1, 2])
+def test_gather_with_an_empty_shard_keeps_every_rank_in_the_exchange(empty_rank):
+    """A rank whose shard is empty (fewer problems than ranks, a filtered batch) still takes part in the gather -- under
+    the nccl backend a rank that sits a batch out can leave its peers' lazy communicator set-up waiting.  Three gloo
+    ranks, the empty one being the root, a middle rank or the last."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 3, port, q, empty_rank)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -62,8 +62,8 @@ def test_single_process_multi_device_path_equals_the_single_handle(ragged, place
             nz = nlp.problem_dims(b)[1]
             assert np.array_equal(vals[j_off[i] : j_off[i] + nz], nlp.split_vals(v1, b)), b
     assert end == batch.B
-    ms = m.time_c_and_jac(1, 3)
-    assert ms.shape == (m.n_devices,) and np.all(ms > 0)
+    ms, wall = m.time_c_and_jac(1, 3)   # one issue thread per device, released together
+    assert ms.shape == (m.n_devices,) and np.all(ms > 0) and wall >= ms.max() * 0.5
     m.close()
 
 
