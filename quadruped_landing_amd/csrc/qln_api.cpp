@@ -288,6 +288,7 @@ int qln_create(const qln_batch_desc* d, int device, qln_handle** out) {
     P.cost_batch = d->cost_batch;
     P.z_stride = z_stride;
     P.jac_format = fmt;
+    P.kt_max = *std::max_element(d->k_trans, d->k_trans + d->B);
     // host-pointer (MOI) mode: up to 8 MB per callback the kernels work on mapped host memory directly (one launch, no
     // copies: 19-21 us against 32 us for the notebook's problem, profiles/r01_moi_latency.txt); larger batches are
     // staged through device memory

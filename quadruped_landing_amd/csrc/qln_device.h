@@ -31,6 +31,7 @@ struct BatchParams {
     int32_t cost_batch;
     int64_t z_stride;
     int32_t jac_format;        // QLN_JAC_FORMAT_*: layout of the step-block section of vals
+    int32_t kt_max;            // largest k_trans of the batch (host-side sizing of the structural format's LDS tile)
 };
 
 // ---------------------------------------------------------------------------------------------

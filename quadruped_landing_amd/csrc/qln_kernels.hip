@@ -120,6 +120,28 @@ __device__ __forceinline__ void drain_full(uint32_t lds, double2* dst) {
     }
 }
 
+// A contiguous run of doubles LDS -> global: s_j[lbeg .. lbeg + len) -> gfirst[0 .. len), with gfirst's address (in
+// doubles) of the same parity as lbeg, so that 16-byte pieces are aligned on both sides.  A leading / trailing half piece
+// goes out as one 8-byte store; the complete pieces as 16 B per lane, 1 KiB per wave instruction, six LDS reads in flight.
+template <bool STREAM>
+__device__ __forceinline__ void drain_run(double* s_j, int lbeg, int len, double* __restrict__ gfirst, int lane) {
+    const int lend = lbeg + len;
+    double* gbase = gfirst - lbeg;  // gbase[i] <-> s_j[i]
+    if (lane == 0) {
+        if (lbeg & 1) gbase[lbeg] = s_j[lbeg];
+        if ((lend & 1) && len > 0) gbase[lend - 1] = s_j[lend - 1];
+    }
+    const int first = (lbeg + 1) >> 1;
+    const int np = (lend >> 1) - first;  // complete pieces
+    double2* dst = reinterpret_cast<double2*>(gbase) + first + lane;
+    const double2* src = reinterpret_cast<const double2*>(s_j) + first + lane;
+    int it = 0;
+#pragma unroll 1
+    for (; (it + 6) * kWave <= np; it += 6) drain6<kWave, STREAM>(lds_offset(src + it * kWave), dst + it * kWave);
+#pragma unroll 1
+    for (; it * kWave + lane < np; ++it) block_store<STREAM>(dst + it * kWave, src[it * kWave]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Objective (src/costs.jl:6-16).  One knot's term with the reference's operation order: the left-to-right sums of
 // 0.5 x'Qx, q'x, 0.5 u'Ru, r'u over a knot's entries (src/quadratic_cost.jl:44-52; Q, R diagonal), then
@@ -217,10 +239,16 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     constexpr int kCStage = (kZSlice + 1) & ~1;
     // structural format: up to 71 values per knot of the chunk, +1 so that the LDS image can start at the parity of
     // its global offset (16-byte pieces then line up on both sides)
-    constexpr int kTile = NNZ ? ((KC * 71 + 2) & ~1) : T * kBlk;
-    static_assert(kTile >= kCStage + KC * 15 + (WITH_F ? kWave : 0), "Z slice + residual stage (+ objective terms) must fit in the tile they alias");
-    static_assert(kTile >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
-    __shared__ double2 s_j2[kTile / 2];
+    // Dense blocks: a static tile of T blocks.  Structural format: the tile is DYNAMIC LDS sized by the host for the batch
+    // (nnz_lds_doubles below: the longest run a sub-tile of this batch can have, the staged slice and the residual stage) --
+    // 71 values per knot is the worst case, a batch whose problems spend most knots in mode 3 (57) needs less, and what a
+    // workgroup does not reserve another can: config 3's problems take 19.1 KB instead of 22.7 KB, 8 waves per CU instead of 7.
+    constexpr int kTile = NNZ ? 2 : T * kBlk;
+    static_assert(NNZ || kTile >= kCStage + KC * 15 + (WITH_F ? kWave : 0), "Z slice + residual stage (+ objective terms) must fit in the tile they alias");
+    static_assert(NNZ || kTile >= ((kZSlice + kWave - 1) / kWave) * kWave, "unpredicated staging writes must fit in the tile");
+    __shared__ double2 s_static2[kTile / 2];
+    extern __shared__ double2 s_dyn2[];
+    double2* const s_j2 = NNZ ? s_dyn2 : s_static2;
     double* const s_j = reinterpret_cast<double*>(s_j2);
     double* const s_z = s_j;
     double* const s_c = s_j + kCStage;
@@ -300,6 +328,10 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     const int o_fc = o_co + (N - kt + 1);
     const int o_bp = o_fc + 1;
     const bool init1 = (im == 1);  // foot 1 touches first: contact-init row is y1, contact-other is y2
+    // (Measured and not adopted, profiles/r03_structural_floor.txt: the whole constraint vector assembled in LDS and written as
+    // one aligned 16-byte-per-lane stream instead of these short 8-byte-per-lane stores -- no difference: the launch sits on
+    // the floor of its memory shape either way.)
+    auto c_put = [&](int idx, double v) { Cb[idx] = v; };
     // length of the step-block section of vals
     const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
     double J_obj = 0.0;  // WITH_F: eval_f accumulated over the chunks, in knot order
@@ -356,10 +388,10 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             if (WITH_C) {
                 // c1 = Z[x_1] - x0 (src/constraints.jl:149), c2 = Z[x_N][1:14] - xf[1:14] (:150),
                 // c6 = F1y + F2y + mb*g of u_{N-1} (:154), all out of the staged slice
-                if (first_chunk && lane < 15) Cb[lane] = s_z[lane] - bnd;
+                if (first_chunk && lane < 15) c_put(lane, s_z[lane] - bnd);
                 if (last_chunk) {
-                    if (lane >= 15 && lane < 29) Cb[lane] = s_z[20 * nk + (lane - 15)] - bnd;
-                    if (lane == 29) Cb[o_fc] = s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g;
+                    if (lane >= 15 && lane < 29) c_put(lane, s_z[20 * nk + (lane - 15)] - bnd);
+                    if (lane == 29) c_put(o_fc, s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g);
                 }
             }
         }
@@ -392,11 +424,11 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             }
             // per-knot scalar rows: contact (src/constraints.jl:48-91) and clearance (:98-113)
             if (valid) {
-                Cb[o_ci + k] = init1 ? x[4] : x[6];
-                if (K >= kt) Cb[o_co + (K - kt)] = init1 ? x[6] : x[4];
+                c_put(o_ci + k, init1 ? x[4] : x[6]);
+                if (K >= kt) c_put(o_co + (K - kt), init1 ? x[6] : x[4]);
                 if (k == N - 2) {  // this lane also holds the terminal knot x_N
-                    Cb[o_ci + k + 1] = init1 ? xnext[4] : xnext[6];
-                    if (K + 1 >= kt) Cb[o_co + (K + 1 - kt)] = init1 ? xnext[6] : xnext[4];
+                    c_put(o_ci + k + 1, init1 ? xnext[4] : xnext[6]);
+                    if (K + 1 >= kt) c_put(o_co + (K + 1 - kt), init1 ? xnext[6] : xnext[4]);
                 }
                 // dynamics residuals: 15 per knot, knot-major and contiguous in c
                 // (src/constraints.jl:14-18); transposed through LDS so the store is coalesced
@@ -412,14 +444,14 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 if constexpr (WITH_J) sincos(zk[2], &sth, &cos_th);  // the Jacobian phase needs cos(theta_k) (one call)
                 else sth = sin(zk[2]);
                 const double cl = zk[1] - lb / 2 * fabs(sth);
-                if (own) Cb[o_bp + kc0 + lane] = cl;
+                if (own) c_put(o_bp + kc0 + lane, cl);
                 if (last_chunk && nk == kWave) {  // wave-uniform: a full last chunk has no lane left for x_N
                     const double* zn = s_z + 20 * nk;
                     double stn;
                     if constexpr (WITH_J) sincos(zn[2], &stn, &cos_tn);
                     else stn = sin(zn[2]);
                     const double cn = zn[1] - lb / 2 * fabs(stn);
-                    if (lane == 0) Cb[o_bp + kc0 + nk] = cn;
+                    if (lane == 0) c_put(o_bp + kc0 + nk, cn);
                 }
             }
             wave_lds_sync();
@@ -520,10 +552,16 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 // Every lane writes the values of its knot's pattern (71 / 56 / 57 of them) behind those of
                 // the lane before it; lanes of different contact modes take different branches (at most
                 // three per chunk: before, at and after the transition knot).
-                const int g0 = step_block_offset(kc0, N, kt);
-                const int g1 = step_block_offset(kc0 + nk, N, kt);
+                // T = 0: the whole chunk is one LDS image; T > 0: sub-tiles of T knots, each emitted by its T lanes and
+                // drained before the next (a smaller tile: more waves per CU, the emission's instructions issued once per sub-tile).
+                constexpr int kSub = T > 0 ? T : KC;
+#pragma unroll 1
+                for (int t0 = 0; t0 < nk; t0 += kSub) {
+                const int nkt = min(kSub, nk - t0);
+                const int g0 = step_block_offset(kc0 + t0, N, kt);
+                const int g1 = step_block_offset(kc0 + t0 + nkt, N, kt);
                 const int p0 = g0 & 1;  // the LDS image starts at the parity of its global offset
-                if (valid) {
+                if (valid && lane >= t0 && lane < t0 + nkt) {
                     // One pass over the pattern of the problem's contact mode (71 entries, column-major), the same
                     // instructions for every lane.  Lanes whose knot has a sparser pattern (mode 3: 57, transition
                     // knot: 56) pull their write pointer back by one slot after every entry their pattern lacks, so
@@ -557,26 +595,11 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 }
                 wave_lds_sync();
                 QLN_STAMP(4);
-                {
-                    // LDS double i <-> vals[gb + i]; gb is even, so 16-byte pieces are aligned on both sides.
-                    // A leading / trailing half piece goes out as one 8-byte store.
-                    const int pe = p0 + (g1 - g0);
-                    double* gbase = Vb + (g0 - p0);
-                    if (lane == 0) {
-                        if (p0) gbase[1] = s_j[1];
-                        if (pe & 1) gbase[pe - 1] = s_j[pe - 1];
-                    }
-                    const int np = (pe >> 1) - p0;  // complete pieces, the first one is piece p0
-                    double2* dst = reinterpret_cast<double2*>(gbase) + p0 + lane;
-                    const double2* src = s_j2 + p0 + lane;
-                    int it = 0;
-#pragma unroll 1
-                    for (; (it + 6) * kWave <= np; it += 6) drain6<kWave, STREAM>(lds_offset(src + it * kWave), dst + it * kWave);
-#pragma unroll 1
-                    for (; it * kWave + lane < np; ++it) block_store<STREAM>(dst + it * kWave, src[it * kWave]);
-                }
+                // LDS double p0 + i <-> vals[g0 + i]; j_off is even, so p0 = g0 & 1 lines the 16-byte pieces up on both sides
+                drain_run<STREAM>(s_j, p0, g1 - g0, Vb + g0, lane);
                 wave_lds_sync();
                 QLN_STAMP(5);
+                }  // sub-tiles
             } else {
             // ---- assemble T knots at a time in LDS and stream them out ---------------------------
             const int nt = (nk + T - 1) / T;
@@ -990,6 +1013,29 @@ __global__ __launch_bounds__(256) void k_friction_rows(BatchParams P, const doub
     }
 }
 
+// Dynamic LDS of the structural-format instantiations (bytes): the longest run of vals a sub-tile of `sub` knots can be
+// in this batch -- a chunk's run grows with k_trans (71 values per knot before the transition, 57 after), so the batch's
+// largest k_trans bounds it -- plus the parity slot, and never less than what aliases the tile: the staged slice of Z
+// (written unpredicated in whole wave-rows), the residual stage and, for qln_eval_all, the objective terms.
+inline size_t nnz_lds_bytes(const BatchParams& p, int KC, int sub, bool with_f) {
+    const int N = p.N, kt = std::min(std::max(p.kt_max, 1), N + 1);
+    int longest = 0;
+    for (int kc0 = 0; kc0 < N - 1; kc0 += KC) {
+        const int nk = std::min(KC, N - 1 - kc0);
+        for (int t0 = 0; t0 < nk; t0 += sub) {
+            const int nkt = std::min(sub, nk - t0);
+            // x of the run's knots lie before the transition knot at the batch's largest k_trans (71 values each), and no
+            // problem of the batch has more of them; every other knot has at most 57: 57 nkt + 14 x bounds every problem's run
+            const int x = std::min(nkt, std::max(0, std::min(kt - 2, N - 1) - (kc0 + t0)));
+            longest = std::max(longest, 57 * nkt + 14 * x);
+        }
+    }
+    const int z_slice = KC * 20 + 15, c_stage = (z_slice + 1) & ~1;
+    int need = std::max(c_stage + KC * 15 + (with_f ? kWave : 0), ((z_slice + kWave - 1) / kWave) * kWave);
+    need = std::max(need, longest + 2);
+    return (size_t)((need + 1) & ~1) * sizeof(double);
+}
+
 template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
@@ -1007,7 +1053,8 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
     const bool stream_out = (int64_t)nb * (p.N - 1) * (NNZ ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
     auto go = [&](auto with_c, auto with_j, auto streamed) {
         constexpr bool WC = decltype(with_c)::value, WJ = decltype(with_j)::value, ST = decltype(streamed)::value;
-        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, WC, WJ, NNZ, SPLIT, ST>), grid, block, (WC && WJ) ? pad : 0u, stream, p,
+        const unsigned lds = (NNZ ? (unsigned)nnz_lds_bytes(p, KC, T > 0 ? T : KC, false) : 0u) + ((WC && WJ) ? pad : 0u);
+        hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, WC, WJ, NNZ, SPLIT, ST>), grid, block, lds, stream, p,
                            b_begin, nb, Z, c, vals, flags);
     };
     using yes = std::true_type;
@@ -1068,6 +1115,10 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 13: return launch_cj_t<0, 32, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 14: return launch_cj_t<0, 64, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 15: return launch_cj_t<0, 64, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 16: return launch_cj_t<20, 40, 3, true>(p, b_begin, nb, Z, c, vals, flags, stream);  // two sub-tiles, three waves per SIMD
+        case 17: return launch_cj_t<20, 40, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 18: return launch_cj_t<0, 40, 2, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        case 19: return launch_cj_t<14, 40, 3, true>(p, b_begin, nb, Z, c, vals, flags, stream);
         default: break;
     }
 #endif
@@ -1086,8 +1137,9 @@ hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, dou
     const bool stream_out = (int64_t)nb * (p.N - 1) * (structural ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
     flags &= QLN_JAC_WRITE_CONSTANTS;
     if (structural) {
-        if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
-        else hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+        const unsigned lds = (unsigned)nnz_lds_bytes(p, 40, 40, true);
+        if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, true, true>), grid, block, lds, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+        else hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, false, true>), grid, block, lds, stream, p, 0, nb, Z, c, vals, flags, f, grad);
     } else {
         if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
         else hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
