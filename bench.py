@@ -154,6 +154,42 @@ def cpu_baseline(batch, nlp, Z_dev, budget_s=12.0):
     return one, allc
 
 
+def cpu_solve_baseline(batch, nlp, budget_s=25.0):
+    """A CPU figure beside the solve numbers: the numpy prototype of the SAME method (augmented-Lagrangian iLQR; Riccati sweep
+    per problem) on the C restatement's dynamics and Jacobians -- bench/solver_prototype.py, the development aid the kernel was
+    designed with: one thread, Python loops over the knots, its own (first, exact-inner-solve) penalty schedule.  Not Ipopt (not
+    installed; the reference's own Ipopt run of the notebook problem: 428 iterations, 594 s, "Restoration Failed",
+    src/main.ipynb:707-727), not tuned: a reported baseline for scale, on a bounded sample of the same problems."""
+    import contextlib
+    import importlib.util
+    import io
+
+    spec = importlib.util.spec_from_file_location("solver_prototype", os.path.join(ROOT, "bench", "solver_prototype.py"))
+    SP = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SP)
+    from quadruped_landing_amd.ref_traj import reference_trajectory
+
+    obj = nlp.get_cost()
+    x0, xf = nlp.boundary_states()
+    done, solved, iters = 0, 0, []
+    t0 = time.perf_counter()
+    while done < batch.B and (done == 0 or (time.perf_counter() - t0) * (done + 1) / done < budget_s):
+        b = done
+        cost = obj if obj.ndim == 2 else obj[b]
+        p = SP.Problem(batch.N, int(batch.k_trans[b]), int(batch.init_mode[b]), x0[b], xf[b], cost)
+        _, Ur = reference_trajectory(batch.model, batch.N, batch.k_trans[b:b + 1], xf[b:b + 1], batch.init_mode[b:b + 1], 0.009)
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, _, _, viol, it = SP.solve(p, Ur[0], verbose=False)
+        done += 1
+        solved += int(viol <= 1e-6)
+        iters.append(it)
+    dt = time.perf_counter() - t0
+    return {"solved_problems_per_s": solved / dt, "cores": 1, "kind": "port", "problems": done, "solved_to_1e-6": solved,
+            "wall_s": dt, "ilqr_iterations_median": float(np.median(iters)),
+            "sample": f"the first {done} problems of the same batch, {dt:.1f} s; numpy prototype of the same AL-iLQR on the C "
+                      "restatement's dynamics (bench/solver_prototype.py): 1 thread, Python loops, exact inner solves -- not Ipopt, not tuned"}
+
+
 def kernel_build_id():
     """Hash of the kernel sources the loaded library was built from: measured HBM traffic (profiles/traffic.json) is
     only quoted for the build it was taken on."""
@@ -582,6 +618,8 @@ def run_ranks(args):
                 "violation_max": float(sviol.max()), "objective_median": float(np.median(si[:, 2])),
                 "note": "qln_solve (augmented-Lagrangian iLQR, one wave per problem) from qln_initial_guess's Z0; violation = "
                         "qln_constraint_violation of the returned Z (Ipopt's definition)"}
+            if not args.no_cpu_baseline:
+                out["other"]["solve_config2_B1024_N40"]["cpu_baseline"] = cpu_solve_baseline(b2, n2)
             del b2, n2, Z2, c2, v2, Zs
             # ... and every problem of the bench workload itself (65 536 of them at the default): the large-batch regime,
             # two waves per SIMD (uniform workloads; the ragged one draws transition knots no landing is feasible for)

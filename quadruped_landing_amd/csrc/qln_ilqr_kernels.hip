@@ -123,6 +123,49 @@ __device__ __forceinline__ void fmac5_row_bcast(double (&u)[5], const double (&K
             : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(dx), "n"(I));
     }
 }
+// acc += (lane I0 + i of the row's `rec`) * v[i], i = 0 .. n-1: the same DPP-operand multiply-add, for the stage cost of the
+// merit evaluation -- a knot's 41-double cost record lies across the sixteen lanes of the lane group that evaluates it
+// (three registers: rec[0..15], rec[16..31], rec[32..40]), fetched with three coalesced loads a batch ahead, instead of every
+// lane issuing 41 loads of its own where the value is needed.  One leading s_nop covers the DPP hazards (see above).
+template <int I0, int NOP>
+__device__ __forceinline__ void fmac_row_bcast_8(double& acc, double rec, double v0, double v1, double v2, double v3, double v4,
+                                                 double v5, double v6, double v7) {
+    static_assert(I0 >= 0 && I0 + 7 < 16, "lanes of the row");
+    asm("s_nop %10\n\t"
+        "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %6 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %7 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %8 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %9 row_newbcast:%18 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(rec), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "n"(NOP), "n"(I0), "n"(I0 + 1),
+          "n"(I0 + 2), "n"(I0 + 3), "n"(I0 + 4), "n"(I0 + 5), "n"(I0 + 6), "n"(I0 + 7));
+}
+template <int I, int NOP>
+__device__ __forceinline__ void fmac_row_bcast_1(double& acc, double rec, double v) {
+    asm("s_nop %3\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rec), "v"(v), "n"(NOP), "n"(I));
+}
+// l_k(x, u) of a stage knot from the record held across the row (see above): sum_e D_e (z_e^2 / 2) + d_e z_e + c, z = [x; u].
+// Eight terms per block, so that only eight squares are live at a time; two independent chains.
+__device__ __forceinline__ double stage_ell_row(const double (&cr)[3], const double (&x)[15], const double (&u)[5]) {
+    auto hsq = [](double z) { return 0.5 * z * z; };
+    double a0 = 0.0, a1 = 0.0;
+    // rec[0..15] = D_0 .. D_15 (the squares of x_0..x_14, u_0)
+    fmac_row_bcast_8<0, 4>(a0, cr[0], hsq(x[0]), hsq(x[1]), hsq(x[2]), hsq(x[3]), hsq(x[4]), hsq(x[5]), hsq(x[6]), hsq(x[7]));
+    // rec[20..31] = d_0 .. d_11 at lanes 4..15 of the second register
+    fmac_row_bcast_8<8, 1>(a1, cr[1], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11]);
+    fmac_row_bcast_8<8, 1>(a0, cr[0], hsq(x[8]), hsq(x[9]), hsq(x[10]), hsq(x[11]), hsq(x[12]), hsq(x[13]), hsq(x[14]), hsq(u[0]));
+    // rec[16..19] = D_16 .. D_19 (u_1..u_4), rec[20..23] = d_0 .. d_3
+    fmac_row_bcast_8<0, 1>(a1, cr[1], hsq(u[1]), hsq(u[2]), hsq(u[3]), hsq(u[4]), x[0], x[1], x[2], x[3]);
+    // rec[32..39] = d_12 .. d_19, rec[40] = c
+    fmac_row_bcast_8<0, 1>(a0, cr[2], x[12], x[13], x[14], u[0], u[1], u[2], u[3], u[4]);
+    fmac_row_bcast_1<8, 1>(a1, cr[2], 1.0);
+    return a0 + a1;
+}
+
 template <int... I, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -163,13 +206,17 @@ struct StageOut {
 };
 
 // Augmented-Lagrangian stage cost of one knot (src/costs.jl:6-16 for the objective part).  x[15], u[5] in registers.
-__device__ __forceinline__ void stage_eval(const StageIn& I, const double (&x)[15], const double (&u)[5], StageOut& o) {
-    double ell = I.rec[40];
+template <bool ELL_GIVEN = false>
+__device__ __forceinline__ void stage_eval(const StageIn& I, const double (&x)[15], const double (&u)[5], StageOut& o, double ell_in = 0.0) {
+    double ell = ell_in;
+    if constexpr (!ELL_GIVEN) {
+        ell = I.rec[40];
 #pragma unroll
-    for (int i = 0; i < 15; ++i) ell += (0.5 * (I.rec[i] * x[i])) * x[i] + I.rec[20 + i] * x[i];
-    if (I.has_u) {
+        for (int i = 0; i < 15; ++i) ell += (0.5 * (I.rec[i] * x[i])) * x[i] + I.rec[20 + i] * x[i];
+        if (I.has_u) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) ell += (0.5 * (I.rec[15 + i] * u[i])) * u[i] + I.rec[35 + i] * u[i];
+            for (int i = 0; i < 5; ++i) ell += (0.5 * (I.rec[15 + i] * u[i])) * u[i] + I.rec[35 + i] * u[i];
+        }
     }
     o.ell = ell;
     double val = I.w * ell;
@@ -1031,6 +1078,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                     for (int j = 0; j < kIneq; ++j) lo[j] = lamg[kIneq * kq + j];
                 };
                 fetch_lam(grp, lr);
+                // ... and so is the cost record of the knot a lane group evaluates: across the group's sixteen lanes, three
+                // coalesced loads (stage_ell_row), instead of 41 loads per lane at the point of use
+                double cr[3];
+                auto fetch_rec = [=](int kk, double (&c3)[3]) {
+                    const double* __restrict__ r = costg + 41 * min(max(kk, 0), N - 2);
+                    c3[0] = r[a];
+                    c3[1] = r[16 + a];
+                    c3[2] = r[32 + min(a, 8)];
+                };
+                fetch_rec(grp, cr);
                 wave_lds_sync();
                 for (int k = 0; k < N - 1; ++k) {
                     QLN_ROLL_BEGIN();
@@ -1079,10 +1136,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_al_ilqr(BatchParams P, SolvePara
                             StageIn I = stage_in(kk, rho, w);
                             I.lam5 = lr;
                             StageOut o;
-                            stage_eval(I, xs, us, o);
+                            stage_eval<true>(I, xs, us, o, stage_ell_row(cr, xs, us));
                             J += o.val;
                         }
                         fetch_lam(kb + kGroups + grp, lr);
+                        fetch_rec(kb + kGroups + grp, cr);
                     }
                     QLN_ROLL_TICK(tk_roll);
                 }
