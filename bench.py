@@ -70,9 +70,13 @@ def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks",
     from quadruped_landing_amd import HybridNLP, PlanarQuadruped, problem_gen as PG
 
     w = WORKLOADS[workload]
-    if w["ragged"] or host_data:
-        # host generator (numpy): the ragged workload's per-problem k_trans / init_mode draws have no closed-form position
-        # in the PCG64 stream.  Per-problem cost tables (config 4: 1.7 GB) are built on the device, not uploaded.
+    ragged_off = None
+    if w["ragged"] and not host_data:
+        # config 4's descriptors drawn on the device with numpy's own algorithm and stream positions; usable unless numpy
+        # would have rejected a draw for this seed (probability 3e-4 at this size), which shifts the stream behind it
+        kt, im, ragged_off = PG.ragged_descriptors(seed, w["B"], w["N"], device=device)
+    if (w["ragged"] and ragged_off is None) or host_data:
+        # host generator (numpy), uploaded.  Per-problem cost tables (config 4: 1.7 GB) are built on the device, not uploaded.
         batch = PG.make_batch(w["B"], w["N"], w["k_trans"] or 14, 1, seed=seed, ragged=w["ragged"], build_obj=not w["ragged"])
         nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
                         device=device, stream=torch.cuda.current_stream(), jac_format=jac_format)
@@ -86,16 +90,22 @@ def build(workload, seed, device, placement_trials=1, jac_format="dense_blocks",
         # guess and its N(0, 0.05^2) perturbation -- nothing but the descriptors is uploaded
         model = PlanarQuadruped()
         B, N = w["B"], w["N"]
-        kt = np.full(B, w["k_trans"], dtype=np.int32)
-        im = np.full(B, 1, dtype=np.int32)
+        off = 0
+        if not w["ragged"]:
+            kt = np.full(B, w["k_trans"], dtype=np.int32)
+            im = np.full(B, 1, dtype=np.int32)
+        else:
+            off = ragged_off  # the integers consumed the first B outputs of the stream
         xf = np.tile(PG.terminal_state(model), (B, 1))
         nlp = HybridNLP(model, None, im, kt, N, np.zeros((B, 15)), xf, device=device, stream=torch.cuda.current_stream(),
                         jac_format=jac_format)
-        x0 = nlp.sample_drop_states(PG.drop_state_sampler(seed, model))
-        nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=False)
-        Z = nlp.perturb_point(nlp.initial_guess(), PG.drop_state_sampler(seed, model, stream_offset=4 * B), sigma=0.05)
+        x0 = nlp.sample_drop_states(PG.drop_state_sampler(seed, model, stream_offset=off))
+        nlp.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=w["ragged"])
+        Z = nlp.perturb_point(nlp.initial_guess(), PG.drop_state_sampler(seed, model, stream_offset=off + 4 * B), sigma=0.05,
+                              redraw_h=w["ragged"])
         batch = PG.LandingBatch(model, N, kt, im, x0, xf, None, None)  # Z stays on the device (cpu_baseline fetches it)
-        build.last_data = "generated on the device (qln_sample_drop_states / qln_set_lqr_cost / qln_initial_guess / qln_perturb_point)"
+        build.last_data = ("generated on the device (" + ("qln_sample_bounded_integers / " if w["ragged"] else "") +
+                           "qln_sample_drop_states / qln_set_lqr_cost / qln_initial_guess / qln_perturb_point)")
     c = nlp.new_c()
     # setup: the long-lived output buffer is allocated once; among `placement_trials` candidate allocations the one
     # whose physical placement sustains the best store bandwidth is kept (HybridNLP.new_vals_placed)
@@ -232,8 +242,8 @@ def main():
                     help="1 = the Jacobian buffer is a plain allocation; > 1 = it is placed across two 32-GiB regions of device "
                          "memory at setup (HybridNLP.new_vals_placed), falling back to this many timed candidate allocations")
     ap.add_argument("--host-data", action="store_true",
-                    help="generate the synthetic workload on the host with numpy and upload it (the default for the uniform "
-                         "workloads is the device-side generator; the ragged workload is always generated on the host)")
+                    help="generate the synthetic workload on the host with numpy and upload it (the default is the device-side "
+                         "generator; the ragged workload falls back to the host for a seed whose integer draws numpy would reject)")
     ap.add_argument("--mode", default="auto", choices=["auto", "ranks", "single-process"],
                     help="how N GPUs are driven: 'ranks' = one process per GPU (a launcher set WORLD_SIZE/RANK/LOCAL_RANK: the "
                          "driver's torch.distributed.run line), RCCL through qln_comm_*; 'single-process' = this process "

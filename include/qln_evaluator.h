@@ -287,6 +287,18 @@ typedef struct qln_drop_state_sampler {
     double two_g;                                          /* 2 * 9.81 in the recipe */
 } qln_drop_state_sampler;
 int qln_sample_drop_states(qln_handle* h, const qln_drop_state_sampler* s);
+/* The ragged workload's per-problem descriptors drawn on the device (k_trans ~ U{2..N-1},
+ * init_mode ~ U{1,2}; 8f-3): numpy.random.Generator.integers(low, high, size = count) on the PCG64 stream -- Lemire's
+ * multiply-shift on 32-bit draws, the low half of a 64-bit output first -- starting `draw_offset` 32-BIT draws into the
+ * stream.  out: HOST array [count] (the draws are made on `device` and copied back: they are the descriptors qln_create is
+ * given).  numpy REJECTS a draw with probability < (high - low) / 2^32 and redraws, which shifts every later position of
+ * the stream by one: *rejected returns how many draws of this call numpy would have rejected, and unless it is 0 the
+ * output -- and every stream position behind this call, e.g. a qln_drop_state_sampler.stream_offset computed from the
+ * draw count -- is NOT numpy's: fall back to the host generator for that seed.  (Two such calls of count B each consume
+ * exactly B 64-bit outputs: the drop states then start at stream_offset = B.  A range of ONE value consumes no draw at
+ * all, as in numpy.)  Needs no handle. */
+int qln_sample_bounded_integers(int device, const uint64_t pcg_state[2], const uint64_t pcg_inc[2], int64_t draw_offset, int32_t low,
+                                int32_t high /* exclusive */, int64_t count, int32_t* out, int64_t* rejected);
 /* Z <- Z + N(0, sigma^2) on every entry, step lengths h then clipped to [h_min, h_max] (redraw_h = 0) or redrawn
  * U(h_min, h_max) (redraw_h != 0) -- the evaluation point of SURVEY.md 8d from qln_initial_guess's Z0.  The normal
  * draws are Box-Muller on the sampler's stream from `stream_offset`: the recipe's distribution, not numpy's numbers. */
@@ -334,6 +346,16 @@ int qln_eval_constraint_jacobian_dense_host(qln_handle* h, int32_t b, const doub
  * serving accesses through its old translations if it is ever mapped again (bench/vmm_va_reuse.cpp,
  * profiles/r02_vmm_va_reuse.txt): ~70 GiB of address space per call, of 128 TiB. */
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best);
+/* The same with the transient memory the scan may map beyond j_total doubles chosen by the caller (qln_vals_alloc_placed
+ * = 64 GiB: two region lengths, so the slab contains two region boundaries and the scan has two chances of a clean
+ * straddling window).  32 GiB gives one boundary, 0 maps the buffer as it comes (no scan: a plain allocation's luck).
+ * Measured consequence: profiles/r03_placement_budget.txt.  The virtual range reserved (and retired, see below) is
+ * j_total * 8 + transient_bytes. */
+int qln_vals_alloc_placed_budget(qln_handle* h, const double* Z, double* c, int64_t transient_bytes, double** vals, float* ms_best);
+/* Address space retired by placed allocations in this process so far (their virtual ranges are never returned, see
+ * above) and the cap at which qln_vals_alloc_placed refuses with QLN_ERR_UNSUPPORTED and a message that says so (64 TiB of
+ * the 128 TiB: ~900 default-size calls).  Either pointer may be NULL.  Needs no handle. */
+int qln_vals_placed_address_space(int64_t* retired_bytes, int64_t* cap_bytes);
 int qln_vals_free_placed(qln_handle* h, double* vals);
 /* What the placement scan of a buffer returned by qln_vals_alloc_placed did (each out pointer may be NULL). */
 int qln_vals_placed_info(const qln_handle* h, const double* vals, int64_t* chunk_bytes, int64_t* chunks_scanned,

@@ -145,6 +145,8 @@ SIGNATURES = {
     "qln_solve_host": (C.c_int, [_vp, _dp, C.POINTER(QlnSolveOptions), _dp]),
     "qln_initial_guess": (C.c_int, [_vp, _dp]),
     "qln_sample_drop_states": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler)]),
+    "qln_sample_bounded_integers": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                            _i32p, _i64p]),
     "qln_perturb_point": (C.c_int, [_vp, C.POINTER(QlnDropStateSampler), _dp, C.c_double, C.c_double, C.c_double, C.c_int]),
     "qln_get_boundary_states": (C.c_int, [_vp, _dp, _dp]),
     "qln_set_lqr_cost": (C.c_int, [_vp, _dp, _dp, _dp, C.c_double, C.c_int]),
@@ -156,6 +158,8 @@ SIGNATURES = {
     "qln_eval_constraint_jacobian_dense_host": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "qln_vals_alloc_placed": (C.c_int, [_vp, _dp, _dp, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "qln_vals_free_placed": (C.c_int, [_vp, _dp]),
+    "qln_vals_alloc_placed_budget": (C.c_int, [_vp, _dp, _dp, C.c_int64, C.POINTER(_vp), C.POINTER(C.c_float)]),
+    "qln_vals_placed_address_space": (C.c_int, [_i64p, _i64p]),
     "qln_vals_placed_info": (C.c_int, [_vp, _dp, _i64p, _i64p, _i64p]),
     "qln_time_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }

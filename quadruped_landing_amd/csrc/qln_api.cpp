@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,11 @@ int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // idle at every unmap in that sequence, and is here).  Keeping a released buffer's range reserved costs address space
 // only (~70 GiB of 128 TiB per qln_vals_alloc_placed call); the physical memory is returned.
 constexpr bool kReturnVirtualRange = false;
+// ... so every placed allocation retires its virtual range for the life of the process.  The ranges are counted, reported
+// (qln_vals_placed_address_space) and capped well inside the 128 TiB of user address space: a process that places buffers in
+// a loop gets a clear refusal after ~900 default-size calls instead of a failing hipMemAddressReserve somewhere else.
+constexpr uint64_t kVaCapBytes = (uint64_t)64 << 40;  // 64 TiB: half the address space stays for everything else
+std::atomic<uint64_t> g_va_retired{0};
 
 // sizes of src/nlp.jl:48-87
 int32_t m_nlp_of(int32_t N, int32_t kt) { return 18 * N - kt + 16; }
@@ -745,6 +751,41 @@ int qln_sample_drop_states(qln_handle* h, const qln_drop_state_sampler* s) {
     return QLN_OK;
 }
 
+int qln_sample_bounded_integers(int device, const uint64_t pcg_state[2], const uint64_t pcg_inc[2], int64_t draw_offset, int32_t low,
+                                int32_t high, int64_t count, int32_t* out, int64_t* rejected) {
+    if (!pcg_state || !pcg_inc || !out || !rejected) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_sample_bounded_integers: null pointer");
+    if (draw_offset < 0 || count < 0 || high <= low) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_sample_bounded_integers: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(QLN_ERR_NO_DEVICE, "qln_sample_bounded_integers: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_sample_bounded_integers: bad device ordinal");
+    *rejected = 0;
+    if (count == 0) return QLN_OK;
+    if ((int64_t)high - low == 1) {  // one possible value: numpy fills it in without touching the stream
+        for (int64_t i = 0; i < count; ++i) out[i] = low;
+        return QLN_OK;
+    }
+    QLN_HIP(hipSetDevice(device));
+    qln::DropStateSampler d{};
+    d.state_hi = pcg_state[0], d.state_lo = pcg_state[1];
+    d.inc_hi = pcg_inc[0], d.inc_lo = pcg_inc[1];
+    d.stream_offset = draw_offset;
+    int32_t* d_out = nullptr;
+    unsigned long long* d_rej = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)count * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rej), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_rej, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = qln::launch_bounded_integers(d, (uint32_t)((int64_t)high - low), low, count, d_out, d_rej, nullptr);
+    unsigned long long rej = 0;
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&rej, d_rej, sizeof rej, hipMemcpyDeviceToHost);
+    if (d_out) (void)hipFree(d_out);
+    if (d_rej) (void)hipFree(d_rej);
+    if (e != hipSuccess) return fail(QLN_ERR_HIP, std::string("qln_sample_bounded_integers: ") + hipGetErrorString(e));
+    *rejected = (int64_t)rej;
+    return QLN_OK;
+}
+
 int qln_perturb_point(qln_handle* h, const qln_drop_state_sampler* s, double* Z, double sigma, double h_min, double h_max,
                       int redraw_h) {
     if (int rc = check_handle(h)) return rc;
@@ -976,8 +1017,19 @@ static int time_fused(qln_handle* h, const double* Z, double* c, double* vals, i
 }
 
 int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** vals, float* ms_best) {
+    return qln_vals_alloc_placed_budget(h, Z, c, (int64_t)64 << 30, vals, ms_best);
+}
+
+int qln_vals_placed_address_space(int64_t* retired_bytes, int64_t* cap_bytes) {
+    if (retired_bytes) *retired_bytes = (int64_t)g_va_retired.load();
+    if (cap_bytes) *cap_bytes = (int64_t)kVaCapBytes;
+    return QLN_OK;
+}
+
+int qln_vals_alloc_placed_budget(qln_handle* h, const double* Z, double* c, int64_t transient_bytes, double** vals, float* ms_best) {
     if (int rc = check_handle(h)) return rc;
     if (!Z || !vals) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_alloc_placed: null pointer");
+    if (transient_bytes < 0) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_vals_alloc_placed: negative transient budget");
     *vals = nullptr;
     if (int rc = bind_device(h)) return rc;
     hipMemAllocationProp prop = {};
@@ -1030,7 +1082,16 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
     }
     // two region lengths beyond the buffer: the slab then contains two boundaries, i.e. two chances of a clean
     // straddling window
-    size_t nslab = small ? need : std::min(budget, need + 2 * region + 1);
+    // (a caller with less memory to spare passes a smaller transient budget: one region length gives one boundary)
+    (void)region;
+    const size_t extra = ((size_t)transient_bytes + chunk - 1) / chunk;
+    size_t nslab = small ? need : std::min(budget, need + extra + 1);
+    if (g_va_retired.load() + (uint64_t)nslab * chunk > kVaCapBytes)
+        return abandon(fail(QLN_ERR_UNSUPPORTED,
+                            "qln_vals_alloc_placed: this process has retired " + std::to_string(g_va_retired.load() >> 30) +
+                                " GiB of virtual address space in placed allocations (ranges are never returned: an unmapped address "
+                                "must not be mapped again on this stack); the cap is " + std::to_string(kVaCapBytes >> 30) +
+                                " GiB -- reuse placed buffers instead of re-allocating them, or use plain hipMalloc memory"));
     for (size_t i = 0; i < nslab; ++i) {
         hipMemGenericAllocationHandle_t hd;
         const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
@@ -1047,6 +1108,7 @@ int qln_vals_alloc_placed(qln_handle* h, const double* Z, double* c, double** va
         void* p = nullptr;
         if (hipError_t e = hipMemAddressReserve(&p, va_size, 0, nullptr, 0); e != hipSuccess) return fail_hip("hipMemAddressReserve", e);
         va = static_cast<char*>(p);
+        if (!kReturnVirtualRange) g_va_retired.fetch_add((uint64_t)va_size);  // whatever happens next, this range is spent
     }
     for (size_t i = 0; i < nslab; ++i) {
         if (hipError_t e = hipMemMap(va + i * chunk, chunk, 0, slab[i], 0); e != hipSuccess) return fail_hip("hipMemMap", e);

@@ -153,6 +153,8 @@ struct DropStateSampler {
     double deg2rad, two_g;
 };
 hipError_t launch_sample_drop_states(const BatchParams& p, const DropStateSampler& s, double* bnd, hipStream_t stream);
+hipError_t launch_bounded_integers(const DropStateSampler& s, uint32_t range, int32_t low, int64_t count, int32_t* out,
+                                   unsigned long long* rejected, hipStream_t stream);
 hipError_t launch_perturb_point(const BatchParams& p, const DropStateSampler& s, double* Z, double sigma, double h_lo, double h_hi,
                                 int redraw_h, hipStream_t stream);
 // batched augmented-Lagrangian iLQR solve of the reference NLP (qln_ilqr_kernels.hip)

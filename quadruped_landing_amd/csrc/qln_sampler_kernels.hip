@@ -117,7 +117,38 @@ __global__ __launch_bounds__(256) void k_perturb_point(BatchParams P, DropStateS
     }
 }
 
+// numpy.random.Generator.integers(low, high, size) for a range below 2^32 on the PCG64 stream: Lemire's multiply-shift on
+// 32-bit draws, which numpy takes from the 64-bit outputs low half first, then the high half (numpy/random/src/
+// distributions: buffered_bounded_lemire_uint32 over pcg64_next32; pinned against numpy on the CPU by
+// tests/test_host_logic.py).  Draw j of the call is half (j & 1) of 64-bit output (j >> 1) -- PROVIDED no earlier draw was
+// rejected: numpy redraws when (m mod 2^32) < (2^32 - range) mod range, probability < range / 2^32 per draw, and every
+// rejection shifts all later positions by one.  The kernel counts the draws that would have been rejected; the caller
+// must not use the result (nor any stream position behind it) unless that count is zero.
+__global__ __launch_bounds__(256) void k_bounded_integers(DropStateSampler S, unsigned rng_excl, int low, long long count,
+                                                         int* __restrict__ out, unsigned long long* __restrict__ rejected) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long j = (unsigned long long)S.stream_offset + (unsigned long long)i;  // in 32-bit draws
+    const unsigned long long v = pcg_output(pcg_advance(u128{S.state_hi, S.state_lo}, u128{S.inc_hi, S.inc_lo}, (j >> 1) + 1));
+    const unsigned u32 = (j & 1ull) ? (unsigned)(v >> 32) : (unsigned)(v & 0xffffffffull);
+    const unsigned long long m = (unsigned long long)u32 * rng_excl;
+    const unsigned leftover = (unsigned)(m & 0xffffffffull);
+    if (leftover < rng_excl) {
+        const unsigned threshold = (0xffffffffu - (rng_excl - 1u)) % rng_excl;
+        if (leftover < threshold) atomicAdd(rejected, 1ull);
+    }
+    out[i] = low + (int)(m >> 32);
+}
+
 }  // namespace
+
+hipError_t launch_bounded_integers(const DropStateSampler& s, uint32_t range, int32_t low, int64_t count, int32_t* out,
+                                   unsigned long long* rejected, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bounded_integers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, s, range, low, (long long)count, out,
+                       rejected);
+    return hipGetLastError();
+}
 
 hipError_t launch_sample_drop_states(const BatchParams& p, const DropStateSampler& s, double* bnd, hipStream_t stream) {
     hipLaunchKernelGGL(k_sample_drop_states, dim3((p.B + 255) / 256), dim3(256), 0, stream, p, s, bnd);

@@ -257,18 +257,25 @@ class HybridNLP:
         _lib.check(_lib.lib().qln_vals_placed_info(self._h, vals.data_ptr(), C.byref(a), C.byref(b), C.byref(c_)))
         return a.value, b.value, c_.value
 
-    def new_vals_regions(self, Z, c=None):
+    @staticmethod
+    def placed_address_space():
+        """(bytes of virtual address space retired by placed allocations in this process, the cap at which the library refuses)"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().qln_vals_placed_address_space(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def new_vals_regions(self, Z, c=None, transient_gib: float = 64.0):
         """The Jacobian buffer placed across two 32-GiB regions of device memory (qln_vals_alloc_placed: HIP
-        virtual-memory API, the fused launch timed on windows of a j_total + 32 GiB range, the fastest window kept and
-        everything else released).  Returns (vals, ms) -- ms = launch time on the window kept.  Raises QlnError if the
-        device has not got j_total*8 + ~33 GiB free or the virtual-memory API fails."""
+        virtual-memory API, the fused launch timed on windows of a j_total + `transient_gib` range, the fastest window kept
+        and everything else released).  Returns (vals, ms) -- ms = launch time on the window kept.  Raises QlnError if the
+        device has not got the memory free or the virtual-memory API fails."""
         t = _torch()
         self._check(Z, self.dims.z_total, "Z")
         if c is not None:  # overwritten by the timed launches; None = the library uses a scratch buffer of its own
             self._check(c, self.dims.c_total, "c")
         ptr, ms = C.c_void_p(), C.c_float()
-        _lib.check(_lib.lib().qln_vals_alloc_placed(self._h, Z.data_ptr(), None if c is None else c.data_ptr(),
-                                                    C.byref(ptr), C.byref(ms)))
+        _lib.check(_lib.lib().qln_vals_alloc_placed_budget(self._h, Z.data_ptr(), None if c is None else c.data_ptr(),
+                                                           int(transient_gib * 2**30), C.byref(ptr), C.byref(ms)))
         vals = t.as_tensor(_PlacedBuffer(self, ptr.value, int(self.dims.j_total)), device=self._dev())
         return vals, float(ms.value)
 

@@ -126,7 +126,8 @@ OMEGA0 = (-np.pi / 2, 0.0)
 def drop_state_sampler(seed: int, model: PlanarQuadruped | None = None, stream_offset: int = 0):
     """The qln_drop_state_sampler that makes qln_sample_drop_states draw exactly what make_batch(seed=seed) draws on
     the host for x0 (uniform k_trans / init_mode batches: the x0 draws are the first 4B of the stream; the ragged
-    workload consumes its k_trans / init_mode integers first, which have no closed-form position -- host only)."""
+    workload consumes its k_trans / init_mode integers first -- B 64-bit outputs when numpy rejects none of them:
+    stream_offset = ragged_descriptors(seed, B, N)[2])."""
     from . import _lib
 
     model = model or PlanarQuadruped()
@@ -142,6 +143,41 @@ def drop_state_sampler(seed: int, model: PlanarQuadruped | None = None, stream_o
         getattr(s, name)[0], getattr(s, name)[1] = float(rng[0]), float(rng[1])
     s.two_g = 2 * 9.81
     return s
+
+
+def ragged_descriptors(seed: int, B: int, N: int, device: int | None = None):
+    """config 4's per-problem descriptors -- k_trans ~ U{2..N-1}, init_mode ~ U{1,2}, exactly make_batch(ragged=True)'s first
+    two draws -- and where the stream stands behind them.  Returns (k_trans, init_mode, stream_offset) with stream_offset
+    the number of 64-bit outputs consumed, i.e. the offset at which qln_sample_drop_states continues numpy's stream -- or
+    None if numpy rejected a draw for this seed (Lemire's method redraws with probability < range / 2^32 per draw, which
+    shifts every later position): the caller then generates the workload on the host.
+    device = None: drawn with numpy on the host, and checked by comparing the generator's state with PCG64(seed) advanced
+    by exactly B outputs.  device = ordinal: drawn on that GPU (qln_sample_bounded_integers), which counts the rejections."""
+    # numpy consumes nothing for a range of one value (N = 3: k_trans = 2 always); 32-bit draws otherwise, two per 64-bit
+    # output -- a buffered odd half is NOT used by the 64-bit uniform draws that follow
+    draws_kt = 0 if N - 2 == 1 else B
+    offset64 = (draws_kt + B + 1) // 2
+    if device is None:
+        rng = np.random.default_rng(seed)
+        kt = rng.integers(2, N, size=B).astype(np.int32)
+        im = rng.integers(1, 3, size=B).astype(np.int32)
+        clean = rng.bit_generator.state["state"] == np.random.PCG64(seed).advance(offset64).state["state"]
+        return kt, im, (offset64 if clean else None)
+    import ctypes as C
+    from . import _lib
+
+    st = np.random.PCG64(seed).state["state"]
+    mask = (1 << 64) - 1
+    state = (C.c_uint64 * 2)(st["state"] >> 64, st["state"] & mask)
+    inc = (C.c_uint64 * 2)(st["inc"] >> 64, st["inc"] & mask)
+    kt, im = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+    rej = C.c_int64()
+    total = 0
+    i32 = C.POINTER(C.c_int32)
+    for out, off, lo, hi in ((kt, 0, 2, N), (im, draws_kt, 1, 3)):
+        _lib.check(_lib.lib().qln_sample_bounded_integers(device, state, inc, off, lo, hi, B, out.ctypes.data_as(i32), C.byref(rej)))
+        total += rej.value
+    return kt, im, (offset64 if total == 0 else None)
 
 
 # Left-right mirror of the planar model about the midpoint of the landed feet (x -> -lb - x, the feet trade names): the

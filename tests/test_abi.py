@@ -115,3 +115,12 @@ def test_multi_create_without_a_gpu_fails_loudly():
     with pytest.raises(_lib.QlnError) as e:
         multi.MultiNLP(b.model, b.obj, b.init_mode, b.k_trans, b.N, b.x0, b.xf, devices=[0])
     assert e.value.code == _lib.QLN_ERR_NO_DEVICE
+
+
+def test_placed_address_space_accounting_needs_no_gpu():
+    """qln_vals_placed_address_space: what placed allocations have retired of the process's address space, and the cap."""
+    L = _lib.lib()
+    a, b = C.c_int64(-1), C.c_int64(-1)
+    assert L.qln_vals_placed_address_space(C.byref(a), C.byref(b)) == _lib.QLN_OK
+    assert a.value >= 0 and b.value == 64 << 40
+    assert L.qln_vals_placed_address_space(None, None) == _lib.QLN_OK

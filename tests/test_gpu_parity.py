@@ -403,6 +403,7 @@ def test_dense_host_jacobian_of_any_problem_in_a_batch_and_two_handles():
 
 def test_region_placed_buffer_gives_the_same_values_and_is_released():
     """qln_vals_alloc_placed: a buffer built with the HIP virtual-memory API behaves like any other device memory."""
+    import ctypes as C
     import torch
     from quadruped_landing_amd import HybridNLP, _lib, problem_gen as PG
 
@@ -427,6 +428,17 @@ def test_region_placed_buffer_gives_the_same_values_and_is_released():
     assert free2 > free1  # released when the tensor went away
     # not a buffer of this handle (any more)
     assert _lib.lib().qln_vals_free_placed(nlp._h, ptr) == _lib.QLN_ERR_INVALID_ARGUMENT
+    # the address space those calls retired is accounted for, and a smaller transient budget works the same way
+    retired, cap = nlp.placed_address_space()
+    assert retired >= 8 * nlp.dims.j_total and cap == 64 << 40
+    v32, ms32 = nlp.new_vals_regions(Z, c, transient_gib=32.0)
+    assert nlp.placed_address_space()[0] > retired and ms32 > 0
+    v32.zero_()
+    nlp.eval_c_and_jac(Z, c, v32, write_constants=True)
+    torch.cuda.synchronize()
+    assert torch.equal(v32, v2)
+    del v32
+    assert _lib.lib().qln_vals_alloc_placed_budget(nlp._h, Z.data_ptr(), None, -1, C.byref(C.c_void_p()), None) == _lib.QLN_ERR_INVALID_ARGUMENT
     # allocate / use / free repeatedly (a freed range's addresses must never serve a later buffer through stale
     # translations: the library keeps its virtual ranges reserved), the last one is left to qln_destroy
     for rep in range(3):

@@ -56,3 +56,30 @@ def test_perturbed_point_has_the_recipes_distribution():
     # the ragged workload's policy: h ~ U(0.001, 0.02)
     Zr = nlp.perturb_point(Z0.clone(), s, sigma=0.05, redraw_h=True).cpu().numpy().reshape(B, -1)[:, hcols]
     assert Zr.min() >= 0.001 and Zr.max() <= 0.02 and abs(Zr.mean() - 0.0105) < 1e-4
+
+
+@pytest.mark.parametrize("B,N,seed", [(1001, 80, 0), (4096, 80, 7), (333, 12, 3), (65536, 80, 5)])
+def test_ragged_workload_generated_on_the_device_is_the_host_generators(B, N, seed):
+    """config 4: k_trans ~ U{2..N-1} and init_mode ~ U{1,2} drawn on the device with numpy's own
+    algorithm and stream positions (qln_sample_bounded_integers), the drop states continuing the stream behind them: all
+    three bit-identical to problem_gen.make_batch(ragged=True), with no rejection reported."""
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    host = PG.make_batch(B, N, seed=seed, ragged=True, build_obj=False)
+    kt, im, off = PG.ragged_descriptors(seed, B, N, device=0)
+    assert off == B and np.array_equal(kt, host.k_trans) and np.array_equal(im, host.init_mode)
+    nlp = HybridNLP(host.model, None, im, kt, N, np.zeros((B, 15)), host.xf)
+    x0 = nlp.sample_drop_states(PG.drop_state_sampler(seed, host.model, stream_offset=off))
+    assert np.array_equal(x0, host.x0)      # incl. the mirrored feet of the init_mode 2 problems
+
+
+def test_a_rejected_draw_is_reported_by_the_device_generator():
+    """Seeds 6076 / 6979 make numpy reject one k_trans draw at B = 65 536, N = 80 (tests/test_host_logic.py): the device
+    generator counts it, and the caller falls back to the host."""
+    from quadruped_landing_amd import problem_gen as PG
+
+    for seed in (6076, 6979):
+        kt, im, off = PG.ragged_descriptors(seed, 65536, 80, device=0)
+        assert off is None
+        assert PG.ragged_descriptors(seed, 65536, 80)[2] is None        # the host check agrees
+    assert PG.ragged_descriptors(6075, 65536, 80, device=0)[2] == 65536

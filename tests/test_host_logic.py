@@ -179,3 +179,41 @@ def test_drop_state_sampler_carries_numpys_pcg64_state():
     assert s.stream_offset == 12 and s.two_g == 2 * 9.81
     assert list(s.x0_template) == list(PG.notebook_initial_state(PG.PlanarQuadruped()))
     assert (s.theta_deg[0], s.theta_deg[1]) == PG.THETA0_DEG and (s.omega[0], s.omega[1]) == PG.OMEGA0
+
+
+def test_ragged_descriptors_are_make_batchs_and_a_rejected_draw_is_detected():
+    """config 4's k_trans / init_mode: numpy's Generator.integers is Lemire's multiply-shift on the 32-bit halves
+    of the PCG64 outputs, low half first, with a rejection step of probability (2^32 mod range) / 2^32 per draw (22 / 2^32 for
+    U{2..79}, never for U{1,2}).  Without a rejection the two calls consume exactly B 64-bit outputs and the drop states follow at
+    stream position B -- what the device-side generator relies on; with one, every later position shifts and the workload must be
+    generated on the host.  Pinned here: (i) an emulation of that algorithm on PCG64's raw outputs reproduces numpy's integers
+    and the stream position behind them (so qln_sample_bounded_integers' kernel, which is the same arithmetic, has a CPU
+    witness); (ii) ragged_descriptors returns make_batch's descriptors; (iii) seeds 6076 and 6979 -- found by scanning -- reject
+    one draw at B = 65 536, N = 80, and are reported as such."""
+    from quadruped_landing_amd import problem_gen as PG
+
+    def emulate(seed, low, high, count, draw_offset):
+        raw = np.random.PCG64(seed).random_raw((draw_offset + count + 1) // 2 + 1)
+        halves = np.empty(2 * raw.size, dtype=np.uint64)
+        halves[0::2], halves[1::2] = raw & np.uint64(0xFFFFFFFF), raw >> np.uint64(32)
+        u = halves[draw_offset: draw_offset + count]
+        r = np.uint64(high - low)
+        m = u * r
+        thr = (0xFFFFFFFF - (high - low - 1)) % (high - low)
+        return (low + (m >> np.uint64(32))).astype(np.int32), int(((m & np.uint64(0xFFFFFFFF)) < thr).sum())
+
+    for seed, B, N in [(0, 1001, 80), (7, 4096, 80), (3, 333, 12), (11, 2, 3), (12, 5, 3)]:
+        kt, im, off = PG.ragged_descriptors(seed, B, N)
+        host = PG.make_batch(B, N, seed=seed, ragged=True, build_obj=False)
+        draws_kt = 0 if N == 3 else B   # a range of one value (N = 3: k_trans = 2) consumes nothing
+        assert off == (draws_kt + B + 1) // 2 and np.array_equal(kt, host.k_trans) and np.array_equal(im, host.init_mode)
+        ekt, r1 = emulate(seed, 2, N, B, 0) if draws_kt else (np.full(B, 2, dtype=np.int32), 0)
+        eim, r2 = emulate(seed, 1, 3, B, draws_kt)
+        assert r1 == 0 and r2 == 0 and np.array_equal(ekt, kt) and np.array_equal(eim, im)
+        # the drop states follow at that 64-bit position: theta0 of make_batch is the uniform drawn there
+        g = np.random.Generator(np.random.PCG64(seed).advance(off))
+        assert np.array_equal(np.deg2rad(g.uniform(*PG.THETA0_DEG, size=B)), host.x0[:, 2])
+    for seed in (6076, 6979):
+        assert PG.ragged_descriptors(seed, 65536, 80)[2] is None
+        assert emulate(seed, 2, 80, 65536, 0)[1] == 1
+    assert PG.ragged_descriptors(6075, 65536, 80)[2] == 65536
