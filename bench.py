@@ -227,6 +227,17 @@ def measured_traffic(key):
     return e.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, {e.get('profile', 'profiles/')}"
 
 
+def stamped_profile_ms(key, placed):
+    """The rocprofv3 kernel average of the newest tracked profile round of this workload (profiles/traffic.json, filed by
+    bench/collect_profiles.py), or None: bench.py puts it beside its own live HIP-event average when the two differ by more
+    than 5 % (another box, or a kernel that changed since the profile)."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key) or {}
+    except Exception:
+        return None, None
+    return e.get("kernel_avg_ms_rocprof_placed" if placed else "kernel_avg_ms_rocprof_plain"), e.get("build_id")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,8 +326,17 @@ def roofline_record(args, batch, ms_each):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     strict = float(np.sum(strict_bytes(batch.N, batch.k_trans)))
     strict_achieved = strict / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_note = measured_traffic(args.workload + ("_structural" if structural else ""))
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    key = args.workload + ("_structural" if structural else "")
+    traffic, traffic_note = measured_traffic(key)
+    prof_ms, prof_build = stamped_profile_ms(key, args.placement_trials > 1)
+    check = {}
+    if prof_ms:
+        check["profile_launch_ms_avg"] = prof_ms
+        if abs(prof_ms - avg_ms) > 0.05 * prof_ms:
+            check["profile_vs_live"] = (f"live HIP-event average {avg_ms:.4f} ms vs {prof_ms:.4f} ms in the tracked rocprofv3 round (kernel build "
+                                        f"{prof_build}; this build {kernel_build_id()}): more than 5 % apart -- another box's placement luck or a "
+                                        "changed kernel; profiles/ROUNDS.md lists every round")
+    return {**check, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_note,
             "kernel": "k_constraint_jacobian", "launch_ms_avg": avg_ms, "launch_ms_min": float(np.min(ms_each)),
             "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_knot_eval": alg_bytes / (batch.B * batch.N),

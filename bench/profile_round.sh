@@ -2,7 +2,9 @@
 # usage (on the GPU box, via gpurun):  bench/profile_round.sh r01 [workload] [dense_blocks|structural]
 # 1. rocprofv3 --kernel-trace --stats of the default bench command  -> kernel_stats.csv
 # 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ set)          -> pmc_summary.txt, traffic.json
-# Everything lands in gpurun_out/profile_<tag>/ ; copy what should be judged into profiles/.
+# Everything lands in gpurun_out/profile_<tag>/ (a fresh tag per round of profiling: nothing is overwritten);
+# bench/collect_profiles.py then files every such directory under profiles/ as <round>_<key>_<n>_*, n counting up, and
+# rewrites profiles/ROUNDS.md (one line per profile round) and profiles/traffic.json (the newest round per workload).
 TAG=${1:-r01}; WL=${2:-config3}; FMT=${3:-dense_blocks}
 KEY=$WL; [ "$FMT" = structural ] && KEY=${WL}_structural
 export TMPDIR=/tmp
@@ -47,9 +49,25 @@ fetch=2*vals["FETCH_SIZE"]*1024; write=vals["WRITE_SIZE"]*1024
 import sys
 sys.path.insert(0, "$R")
 import bench
+import csv
+def avg_ms(path):
+    try:
+        r = [x for x in csv.DictReader(open(path)) if "k_constraint_jacobian" in x["Name"]]
+        return float(r[0]["AverageNs"]) / 1e6
+    except Exception:
+        return None
+def events_ms(path):
+    try:
+        return json.load(open(path))["roofline"]["launch_ms_avg"]
+    except Exception:
+        return None
 json.dump({"$KEY":{"hbm_bytes_per_launch":fetch+write,"fetch_bytes_corrected":fetch,"write_bytes":write,
   "FETCH_SIZE_KiB_raw":vals["FETCH_SIZE"],"WRITE_SIZE_KiB_raw":vals["WRITE_SIZE"],
   "build_id":bench.kernel_build_id(),"profile":"profiles/${TAG}_pmc_summary_$KEY.txt",
+  "kernel_avg_ms_rocprof_placed":avg_ms("$OUT/kernel_stats_placed_timed_launches.csv"),
+  "kernel_avg_ms_hip_events_placed":events_ms("$OUT/bench_under_rocprof_placed.json"),
+  "kernel_avg_ms_rocprof_plain":avg_ms("$OUT/kernel_stats.csv"),
+  "kernel_avg_ms_hip_events_plain":events_ms("$OUT/bench_under_rocprof.json"),
   "note":"per launch of k_constraint_jacobian; fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024"}},
   open("$OUT/traffic.json","w"),indent=1)
 print(open("$OUT/traffic.json").read())
