@@ -1065,6 +1065,16 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
     return hipGetLastError();
 }
 
+// constraint-only launch of one instantiation (eval_c! alone: what a line search or Ipopt's eval_constraint callback asks for)
+template <int T, int KC, int W>
+hipError_t launch_c_only_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, hipStream_t stream) {
+    dim3 grid(xcd_grid(nb)), block(kWave);
+    const bool stream_out = (int64_t)nb * (18 * p.N + 16) * 8 > ((int64_t)512 << 20);
+    if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, true>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, 0u);
+    else hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, false>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, 0u);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 #ifdef QLN_DIAG
@@ -1101,6 +1111,16 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         default: break;
     }
+    if (!vals) switch (variant) {  // constraint-only launch: chunk size / tile (= LDS) / register budget
+        case 31: return launch_c_only_t<5, 40, 2>(p, b_begin, nb, Z, c, stream);
+        case 32: return launch_c_only_t<5, 40, 3>(p, b_begin, nb, Z, c, stream);
+        case 33: return launch_c_only_t<5, 40, 4>(p, b_begin, nb, Z, c, stream);
+        case 34: return launch_c_only_t<8, 64, 3>(p, b_begin, nb, Z, c, stream);
+        case 35: return launch_c_only_t<8, 64, 4>(p, b_begin, nb, Z, c, stream);
+        case 36: return launch_c_only_t<4, 32, 3>(p, b_begin, nb, Z, c, stream);
+        case 37: return launch_c_only_t<4, 32, 4>(p, b_begin, nb, Z, c, stream);
+        default: break;
+    }
     switch (variant) {  // small-batch launches: one workgroup per chunk
         case 21: if (p.jac_format == QLN_JAC_FORMAT_DENSE_BLOCKS) return launch_cj_t<16, 16, 1, false, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
         case 22: if (p.jac_format == QLN_JAC_FORMAT_DENSE_BLOCKS) return launch_cj_t<8, 8, 2, false, true>(p, b_begin, nb, Z, c, vals, flags, stream); break;
@@ -1122,7 +1142,15 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         default: break;
     }
 #endif
-    if (!vals) return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
+    if (!vals) {
+        // constraint-only launch (eval_c! alone: a line search's or Ipopt's eval_constraint call): no tile to fill, so the LDS holds
+        // only the staged slice and the residual stage.  40-knot chunks (12 KB of LDS, 13 staging registers per lane) where
+        // they make no more passes than 64-knot chunks would (N <= 41, 66 <= N <= 81, ...): 0.157 -> 0.149 ms at config 3
+        // (profiles/r03_c_only_variants.txt; three or four waves per SIMD need <= 168 / 128 VGPRs and spill: 0.18 / 0.30 ms)
+        const int knots = p.N - 1;
+        if ((knots + 39) / 40 == (knots + 63) / 64) return launch_c_only_t<5, 40, 2>(p, b_begin, nb, Z, c, stream);
+        return launch_c_only_t<8, 64, 2>(p, b_begin, nb, Z, c, stream);
+    }
     // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
     if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
     return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
