@@ -482,6 +482,10 @@ def run_ranks(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("QLN_BENCH_REHEARSE_ON_DEVICE0") == "1":
+        # rehearsal of the N > 1 control flow on a one-GPU box (tests / profiles only): every rank uses device 0; RCCL refuses two
+        # ranks on one device, so this goes with QLN_BENCH_SIMULATE_RCCL_FAILURE=1 (the tail then travels over gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("QLN_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
     multi_rank = world > 1 or force_dist

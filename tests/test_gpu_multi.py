@@ -111,3 +111,32 @@ def test_sharded_solve_and_the_gather_of_final_results():
     Z1, info1 = one.solve(one.initial_guess())
     assert np.array_equal(one.eval_f(Z1).cpu().numpy(), f)
     m.close()
+
+
+def test_bench_two_rank_control_flow_rehearsal_on_one_gpu(tmp_path):
+    """The driver's N > 1 line -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- rehearsed with
+    two ranks on the ONE GPU of this box: both ranks use device 0 (QLN_BENCH_REHEARSE_ON_DEVICE0) and, since RCCL refuses two
+    ranks on one device, the end-of-job tail travels over gloo (QLN_BENCH_SIMULATE_RCCL_FAILURE).  Everything else of the
+    N > 1 control flow runs as it will on a node: the rendezvous, per-rank shards with seed = rank, the barrier-bracketed
+    K-launch region with the max over ranks, the gather of 2 x B per-problem results to rank 0, ONE JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.helpers import ROOT
+
+    env = dict(os.environ, QLN_BENCH_REHEARSE_ON_DEVICE0="1", QLN_BENCH_SIMULATE_RCCL_FAILURE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--workload",
+           "config2", "--placement-trials", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints, one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    B, N = d["config"]["problems_per_gpu"], d["config"]["knots"]
+    assert abs(d["value"] - 2 * B * N / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]   # whole-job aggregate over both ranks
+    assert "RCCL UNAVAILABLE" in d["config"]["driver"] and d["gather_ms"] > 0 and d["gather_c_ms"] > 0
+    assert d["roofline"]["launch_ms_avg"] <= d["ms_per_step"] * 1.5
