@@ -38,6 +38,15 @@ namespace qln {
 #ifdef QLN_DIAG
 __device__ unsigned long long* g_stamps = nullptr;
 #endif
+#ifdef QLN_TUNING
+// tuning build only (QLN_FLOOR=1, profiles/r03_structural_floor.txt): the launch's memory shape on the very same buffers with
+// (nearly) no arithmetic -- the RK4 step, the trigonometry and the structural pattern walk are skipped, every load, store and
+// drain stays.  What is left between that and the real launch is arithmetic the launch does not hide.
+__device__ int g_floor_mode = 0;
+#define QLN_FLOOR_MODE (g_floor_mode != 0)
+#else
+#define QLN_FLOOR_MODE false
+#endif
 
 namespace {
 
@@ -416,7 +425,12 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             sc.a2x = f2free ? (-u[2] / mf) : 0.0;
             sc.a2y = f2free ? (-u[3] / mf + g) : 0.0;
             double xn[15];
-            rk4_step(x, u, sc, f1free, f2free, Ib, xn);
+            if (!QLN_FLOOR_MODE) {
+                rk4_step(x, u, sc, f1free, f2free, Ib, xn);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 15; ++i) xn[i] = x[i];
+            }
             if (jump) {  // jump1_map / jump2_map, src/planar_quadruped.jl:250-260
                 xn[4] = 0.0;
                 xn[6] = 0.0;
@@ -441,7 +455,8 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const bool own = valid || (last_chunk && lane == nk);
                 const double* zk = s_z + 20 * (own ? lane : 0);
                 double sth;
-                if constexpr (WITH_J) sincos(zk[2], &sth, &cos_th);  // the Jacobian phase needs cos(theta_k) (one call)
+                if (QLN_FLOOR_MODE) sth = zk[2], cos_th = 1.0;
+                else if constexpr (WITH_J) sincos(zk[2], &sth, &cos_th);  // the Jacobian phase needs cos(theta_k) (one call)
                 else sth = sin(zk[2]);
                 const double cl = zk[1] - lb / 2 * fabs(sth);
                 if (own) c_put(o_bp + kc0 + lane, cl);
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                 const int g0 = step_block_offset(kc0 + t0, N, kt);
                 const int g1 = step_block_offset(kc0 + t0 + nkt, N, kt);
                 const int p0 = g0 & 1;  // the LDS image starts at the parity of its global offset
-                if (valid && lane >= t0 && lane < t0 + nkt) {
+                if (valid && lane >= t0 && lane < t0 + nkt && !QLN_FLOOR_MODE) {
                     // One pass over the pattern of the problem's contact mode (71 entries, column-major), the same
                     // instructions for every lane.  Lanes whose knot has a sparser pattern (mode 3: 57, transition
                     // knot: 56) pull their write pointer back by one slot after every entry their pattern lacks, so
@@ -1036,11 +1051,24 @@ inline size_t nnz_lds_bytes(const BatchParams& p, int KC, int sub, bool with_f) 
     return (size_t)((need + 1) & ~1) * sizeof(double);
 }
 
+#ifdef QLN_TUNING
+inline void apply_floor_mode() {
+    static const int done = [] {
+        const char* e = getenv("QLN_FLOOR");
+        const int v = e ? atoi(e) : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_mode), &v, sizeof v);
+        return 1;
+    }();
+    (void)done;
+}
+#endif
+
 template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
                        uint32_t flags, hipStream_t stream) {
     dim3 grid(xcd_grid(SPLIT ? nb * ((p.N - 2) / KC + 1) : nb)), block(kWave);
 #ifdef QLN_TUNING
+    apply_floor_mode();
     // tuning build only: extra (unused) dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned pad = [] {
         const char* e = getenv("QLN_PAD_LDS");
