@@ -337,9 +337,9 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     const int o_fc = o_co + (N - kt + 1);
     const int o_bp = o_fc + 1;
     const bool init1 = (im == 1);  // foot 1 touches first: contact-init row is y1, contact-other is y2
-    // (Measured and not adopted, profiles/r03_structural_floor.txt: the whole constraint vector assembled in LDS and written as
-    // one aligned 16-byte-per-lane stream instead of these short 8-byte-per-lane stores -- no difference: the launch sits on
-    // the floor of its memory shape either way.)
+    // every row of c goes through here.  (Measured and not adopted, profiles/r03_structural_floor.txt: the whole constraint
+    // vector assembled in LDS behind the slice and written as ONE aligned 16-byte-per-lane stream instead of these short
+    // 8-byte-per-lane stores -- no difference in the structural format's fused launch, 0.36 ms either way.)
     auto c_put = [&](int idx, double v) { Cb[idx] = v; };
     // length of the step-block section of vals
     const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
