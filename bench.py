@@ -611,6 +611,20 @@ def run_ranks(args):
                 "roofline_frac": all_bytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "qln_eval_all: eval_f + grad_f! + eval_c! + jac_c! from one read of Z; bytes = the hot launch's + the gradient written"}
             del gg
+            # the pair a line search asks for: f and c from one read of Z in one launch (qln_eval_objective_and_constraint)
+            for _ in range(3):
+                nlp.eval_f_and_c(Z, f, c)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+            for a, b_ in ev:
+                a.record()
+                nlp.eval_f_and_c(Z, f, c)
+                b_.record()
+            torch.cuda.synchronize()
+            ms_fc = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+            fc_bytes = float(np.sum(8 * (20 * batch.N - 5) + 8 * (18 * batch.N - batch.k_trans.astype(np.int64) + 16) + 8))
+            out["other"]["objective_and_constraint_one_launch"] = {
+                "launch_ms_avg": ms_fc, "achieved_GBs": fc_bytes / (ms_fc * 1e-3) / 1e9, "roofline_frac": fc_bytes / (ms_fc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "qln_eval_objective_and_constraint: eval_f + eval_c! from one read of Z (no derivatives); bytes = Z read + c and f written"}
         if world == 1 and not args.no_other and not structural:
             # same workload, structural format (only the non-zeros of every step block are written)
             del vals

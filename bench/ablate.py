@@ -24,5 +24,6 @@ print(wl, "fused +consts  : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, val
 print(wl, "J only         : %.3f ms" % t_ms(lambda: nlp.jac_c(Z, vals, write_constants=False)))
 print(wl, "c only         : %.3f ms" % t_ms(lambda: nlp.eval_c(Z, c)))
 print(wl, "objective      : %.3f ms" % t_ms(lambda: nlp.eval_f(Z, f)))
+print(wl, "f + c, 1 launch: %.3f ms" % t_ms(lambda: nlp.eval_f_and_c(Z, f, c)))
 print(wl, "gradient       : %.3f ms" % t_ms(lambda: nlp.grad_f(Z, g)))
 print(wl, "memset vals    : %.3f ms" % t_ms(lambda: vals.zero_()))

@@ -154,6 +154,11 @@ int qln_eval_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
  * problem's slice of Z in LDS for the constraint rows also forms the objective terms and the gradient from it.  Same
  * layouts and the same bits as the separate entry points.  Needs a cost table. */
 int qln_eval_all(qln_handle* h, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags);
+/* The pair a line search -- or Ipopt's filter at a trial point, which calls eval_f and eval_g at the same x (src/moi.jl:1-3,
+ * 10-13; 1696 + 1696 of the reference run's 4222 callbacks, src/main.ipynb:717-722) -- asks for: f = eval_f and c = eval_c!
+ * from ONE read of Z in one launch, no derivatives.  Same layouts and the same bits as qln_eval_objective and
+ * qln_eval_constraint.  Needs a cost table. */
+int qln_eval_objective_and_constraint(qln_handle* h, const double* Z, double* f, double* c);
 int qln_jacobian_init_constants(qln_handle* h, double* vals);
 /* Products with the constraint Jacobian of jac_c! (src/constraints.jl:212-291) at Z, for the caller side of the path
  * (solver iterations on the GPU).  The Jacobian is not read from memory: every step block is re-derived

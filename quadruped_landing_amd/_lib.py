@@ -131,6 +131,7 @@ SIGNATURES = {
     "qln_eval_constraint_jacobian": (C.c_int, [_vp, _dp, _dp, C.c_uint32]),
     "qln_eval_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32]),
     "qln_eval_all": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, C.c_uint32]),
+    "qln_eval_objective_and_constraint": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_jacobian_init_constants": (C.c_int, [_vp, _dp]),
     "qln_eval_constraint_jvp": (C.c_int, [_vp, _dp, _dp, _dp]),
     "qln_eval_constraint_vjp": (C.c_int, [_vp, _dp, _dp, _dp]),

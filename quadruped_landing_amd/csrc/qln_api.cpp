@@ -559,6 +559,15 @@ int qln_eval_all(qln_handle* h, const double* Z, double* f, double* grad, double
     return QLN_OK;
 }
 
+int qln_eval_objective_and_constraint(qln_handle* h, const double* Z, double* f, double* c) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_cost(h)) return rc;
+    if (!Z || !f || !c) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_eval_objective_and_constraint: null pointer");
+    if (int rc = bind_device(h)) return rc;
+    QLN_HIP(qln::launch_objective_and_constraint(h->p, Z, f, c, h->stream));
+    return QLN_OK;
+}
+
 int qln_jacobian_init_constants(qln_handle* h, double* vals) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = check_vals(vals)) return rc;

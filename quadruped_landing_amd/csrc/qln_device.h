@@ -129,6 +129,7 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
                                       double* vals, uint32_t flags, hipStream_t stream);
 hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, double* grad, double* c, double* vals, uint32_t flags,
                            hipStream_t stream);
+hipError_t launch_objective_and_constraint(const BatchParams& p, const double* Z, double* f, double* c, hipStream_t stream);
 hipError_t launch_kinematic_rows(const BatchParams& p, const double* Z, double* d, double* jac_vals, hipStream_t stream);
 hipError_t launch_friction_rows(const BatchParams& p, const double* Z, double mu, double* d, double* jac_vals, hipStream_t stream);
 hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStream_t stream);

@@ -294,9 +294,15 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     // WITH_F: what the objective and the gradient need of the cost table is requested with the slice -- the lane's knot's record
     // (eval_f, lane = knot) and the D_j, d_j of the lane's entries of the slice (grad_f!, lane = entry) -- so that they are in
     // registers when the value phase is over, not a memory round trip after it
-    double oD[WITH_F ? 20 : 1], od[WITH_F ? 20 : 1], oc40 = 0.0, gD[WITH_F ? kStageIters : 1], gd[WITH_F ? kStageIters : 1];
+    // WITH_F without the Jacobian = qln_eval_objective_and_constraint, the pair a line search asks for: no gradient, and the lane's
+    // cost record is read where the objective term is formed, after the value phase -- this launch lives on its two waves per
+    // SIMD (the RK4 step needs ~200 registers) and cannot hold a record in 80 of them from kernel entry as qln_eval_all does.
+    // (Measured and not adopted: the chunk's records staged through LDS with coalesced loads, objective terms first -- the
+    // slice's loop-carried staging registers then spill, 0.28-0.46 ms against 0.22.)
+    constexpr bool kFullF = WITH_F && WITH_J;
+    double oD[kFullF ? 20 : 1], od[kFullF ? 20 : 1], oc40 = 0.0, gD[kFullF ? kStageIters : 1], gd[kFullF ? kStageIters : 1];
     auto request_cost = [&](int kc0) {
-        if constexpr (WITH_F) {
+        if constexpr (kFullF) {
             const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * P.N * 41 : 0);
             const int nk = min(KC, P.N - 1 - kc0);
             const bool last = (kc0 + nk == P.N - 1);
@@ -364,6 +370,24 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
             Vc[i] = v;
         }
     }
+
+    // eval_f (src/costs.jl:6-16) of one chunk: lane = knot, the terminal knot x_N rides on lane nk of the last chunk (a second
+    // pass when that chunk is full); terms are added in knot order.  The lane's record was requested with the slice.
+    auto eval_objective_chunk = [&](int kc0, int nk, bool valid, bool last_chunk) {
+        if constexpr (WITH_F) {
+            const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
+            const bool own = valid || (last_chunk && lane == nk);
+            const int kk = own ? lane : 0;
+            double term;
+            if constexpr (kFullF) term = objective_term_regs(s_z + 20 * kk, oD, od, oc40, valid);
+            else term = objective_term(s_z + 20 * kk, cost + (int64_t)(kc0 + kk) * 41, valid);
+            J_obj = add_terms_in_order(J_obj, own ? term : 0.0, s_c + KC * 15, lane);
+            if (last_chunk && nk == kWave) {  // wave-uniform
+                const double tn = objective_term(s_z + 20 * nk, cost + (int64_t)(N - 1) * 41, false);
+                J_obj = J_obj + tn;
+            }
+        }
+    };
 
     for (int kc0 = kc_begin; kc0 < kc_end; kc0 += KC) {
         const int nk = min(KC, N - 1 - kc0);
@@ -490,22 +514,10 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
 
         // ============================== objective + gradient (eval_f, grad_f!) ==================
         if constexpr (WITH_F) {
-            const double* __restrict__ cost = P.cost + (P.cost_batch > 1 ? (int64_t)b * N * 41 : 0);
-            // eval_f (src/costs.jl:6-16): lane = knot of the chunk, the terminal knot x_N rides on lane nk of the last chunk
-            // (a second pass when that chunk is full); terms are added in knot order
-            {
-                const bool own = valid || (last_chunk && lane == nk);
-                const int kk = own ? lane : 0;
-                const double term = objective_term_regs(s_z + 20 * kk, oD, od, oc40, valid);
-                J_obj = add_terms_in_order(J_obj, own ? term : 0.0, s_c + KC * 15, lane);
-                if (last_chunk && nk == kWave) {  // wave-uniform
-                    const double tn = objective_term(s_z + 20 * nk, cost + (int64_t)(N - 1) * 41, false);
-                    J_obj = J_obj + tn;
-                }
-            }
+            eval_objective_chunk(kc0, nk, valid, last_chunk);
             // grad_f! (src/costs.jl:23-34, no d(h l)/dh: quirk Q2): lane = entry of the staged slice, coalesced stores;
             // the slice's last 15 entries are x_{k+1} of the next chunk, or x_N -- the terminal knot -- in the last one
-            {
+            if constexpr (kFullF) {
                 double* __restrict__ Gb = G + (int64_t)b * P.z_stride + 20 * kc0;
                 const int ng = 20 * nk + (last_chunk ? 15 : 0);
 #pragma unroll
@@ -1199,6 +1211,24 @@ hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, dou
     } else {
         if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, true, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
         else hipLaunchKernelGGL((k_constraint_jacobian<16, 64, 1, true, true, false, false, false, true>), grid, block, 0, stream, p, 0, nb, Z, c, vals, flags, f, grad);
+    }
+    return hipGetLastError();
+}
+
+// eval_f + eval_c! of the whole batch from ONE read of Z (qln_eval_objective_and_constraint): what a line search, or Ipopt's
+// filter at a trial point, asks for -- objective and constraints, no derivatives
+hipError_t launch_objective_and_constraint(const BatchParams& p, const double* Z, double* f, double* c, hipStream_t stream) {
+    const int nb = p.B;
+    dim3 grid(xcd_grid(nb)), block(kWave);
+    const bool stream_out = (int64_t)nb * (18 * p.N + 16) * 8 > ((int64_t)512 << 20);
+    const int knots = p.N - 1;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, stream, p, 0, nb, Z, c, nullptr, 0u, f, nullptr); };
+    if ((knots + 39) / 40 == (knots + 63) / 64) {  // chunk size as for the constraint-only launch
+        if (stream_out) go(k_constraint_jacobian<5, 40, 2, true, false, false, false, true, true>);
+        else go(k_constraint_jacobian<5, 40, 2, true, false, false, false, false, true>);
+    } else {
+        if (stream_out) go(k_constraint_jacobian<8, 64, 2, true, false, false, false, true, true>);
+        else go(k_constraint_jacobian<8, 64, 2, true, false, false, false, false, true>);
     }
     return hipGetLastError();
 }

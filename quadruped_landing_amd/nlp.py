@@ -394,6 +394,14 @@ class HybridNLP:
             self._check(vals, self.dims.j_total, "vals"), flags))
         return f, grad, c, vals
 
+    def eval_f_and_c(self, Z, f=None, c=None):
+        """f and c from one read of Z in one launch (qln_eval_objective_and_constraint): what a line search asks for."""
+        f = self.new_f() if f is None else f
+        c = self.new_c() if c is None else c
+        _lib.check(_lib.lib().qln_eval_objective_and_constraint(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(f, self.B, "f"), self._check(c, self.dims.c_total, "c")))
+        return f, c
+
     def init_jacobian_constants(self, vals):
         _lib.check(_lib.lib().qln_jacobian_init_constants(self._h, self._check(vals, self.dims.j_total, "vals")))
         return vals

@@ -524,3 +524,28 @@ def test_shared_cost_table_kernels_at_their_size_limits(N, kt, im):
     ref = oracle_batch(batch, nlp, want_c=False, want_j=False, want_f=True, want_grad=True, nthreads=8)
     assert np.array_equal(f.cpu().numpy(), ref["f"])
     assert np.array_equal(g.cpu().numpy().reshape(B, -1)[:, : nlp.n_nlp], ref["grad"].reshape(B, -1)[:, : nlp.n_nlp])
+
+
+@pytest.mark.parametrize("B,N,ragged", [(64, 40, False), (5000, 40, False), (33, 61, False), (29, 80, True), (5, 64, False), (3, 65, False),
+                                        (4, 2, False), (7, 130, True), (9, 41, False), (6, 66, True)])
+def test_objective_and_constraint_in_one_launch_give_the_bits_of_the_separate_entry_points(B, N, ragged):
+    """qln_eval_objective_and_constraint: f and c out of one read of Z in one launch -- what a line search asks for -- are bit for
+    bit qln_eval_objective's and qln_eval_constraint's (which are held to the oracle above), at every chunking the launch
+    chooses (40-knot chunks up to N = 41 and from N = 66, 64-knot chunks between), shared and per-problem cost tables."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    batch = PG.make_batch(B, N, min(14, N), 1, seed=B + N, ragged=ragged)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    Z = nlp.upload_Z(batch.Z)
+    nan = float("nan")
+    mk = lambda n: torch.full((n,), nan, dtype=torch.float64, device="cuda")
+    f, c = nlp.eval_f_and_c(Z, mk(B), mk(nlp.dims.c_total))
+    f1, c1 = nlp.eval_f(Z), nlp.eval_c(Z, mk(nlp.dims.c_total))
+    torch.cuda.synchronize()
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert eq(f, f1) and eq(c, c1) and not torch.isnan(f).any()
+    ref = oracle_batch(batch, nlp, want_c=False, want_j=False, want_f=True)
+    assert np.array_equal(f.cpu().numpy(), ref["f"])
+    with pytest.raises(TypeError):
+        nlp.eval_f_and_c(Z.cpu())
