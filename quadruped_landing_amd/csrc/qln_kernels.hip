@@ -1137,8 +1137,8 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
             return launch_cj_t<16, 16, 1, false, true>(p, b_begin, nb, Z, c, vals, flags, stream);
         }
     }
-    // Shipping configuration: T=16 (38.4 KB tile, 4 waves per CU, one per SIMD) when the Jacobian is
-    // written, T=8 / 8 waves per CU for the constraint-only launch (profiles/r01_variants.txt).
+    // Shipping configuration: T=12 (28.8 KB tile, 5 waves per CU) when the Jacobian is written (below), 40- or 64-knot chunks
+    // with two waves per SIMD for the constraint-only launch (profiles/r01_variants.txt, r03_dense_floor.txt, r03_c_only_variants.txt).
 #ifdef QLN_TUNING
     // tuning build only (make tuning -> libqln_hip_tuning.so): QLN_VARIANT selects other instantiations for A/B runs
     static const int variant = [] {
@@ -1193,7 +1193,10 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
     }
     // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
     if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
-    return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+    // dense blocks: a 12-block tile (28.8 KB, 5 waves per CU).  All three tile sizes sit on the launch's floor (profiles/r03_dense_floor.txt);
+    // on region-placed buffers T = 12 is the fastest by 0.5-1 % (config 3: 1.060-1.063 against 1.069-1.074 ms for T = 16, config 4:
+    // 2.155-2.162 against 2.168-2.174 ms; round 1 chose T = 16 on buffers lying in one region)
+    return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
 }
 
 // f, grad, c and the Jacobian values of the whole batch from ONE read of Z (qln_eval_all)
