@@ -370,6 +370,11 @@ int qln_vals_placed_info(const qln_handle* h, const double* vals, int64_t* chunk
  * handle's stream and returns each timed launch's duration from HIP events (milliseconds). */
 int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags,
                                      int32_t warmup, int32_t iters, float* ms_each /*[iters]*/);
+/* The same launches back to back with nothing between them: ONE pair of HIP events around all `iters` launches;
+ * *ms_total = elapsed ms of the whole run (the launches may overlap at their edges: the next one's first workgroups start while
+ * the previous one's last drain).  Average launch time = *ms_total / iters. */
+int qln_time_constraint_and_jacobian_total(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags,
+                                           int32_t warmup, int32_t iters, float* ms_total);
 
 #ifdef __cplusplus
 }

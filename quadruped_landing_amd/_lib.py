@@ -163,6 +163,7 @@ SIGNATURES = {
     "qln_vals_placed_address_space": (C.c_int, [_i64p, _i64p]),
     "qln_vals_placed_info": (C.c_int, [_vp, _dp, _i64p, _i64p, _i64p]),
     "qln_time_constraint_and_jacobian": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+    "qln_time_constraint_and_jacobian_total": (C.c_int, [_vp, _dp, _dp, _dp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }
 
 

@@ -1251,4 +1251,30 @@ int qln_time_constraint_and_jacobian(qln_handle* h, const double* Z, double* c, 
     return rc;
 }
 
+int qln_time_constraint_and_jacobian_total(qln_handle* h, const double* Z, double* c, double* vals, uint32_t flags, int32_t warmup,
+                                           int32_t iters, float* ms_total) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Z || !c || !ms_total || iters < 1 || warmup < 0)
+        return fail(QLN_ERR_INVALID_ARGUMENT, "qln_time_constraint_and_jacobian_total: bad argument");
+    if (int rc = check_vals(vals)) return rc;
+    if (int rc = bind_device(h)) return rc;
+    flags &= QLN_JAC_WRITE_CONSTANTS;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = QLN_OK;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventCreate failed");
+    for (int32_t i = 0; i < warmup && rc == QLN_OK; ++i)
+        if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "warmup launch failed");
+    if (rc == QLN_OK) (void)hipEventRecord(e0, h->stream);
+    for (int32_t i = 0; i < iters && rc == QLN_OK; ++i)
+        if (qln::launch_constraint_jacobian(h->p, 0, h->p.B, Z, c, vals, flags, h->stream) != hipSuccess)
+            rc = fail(QLN_ERR_HIP, "timed launch failed");
+    if (rc == QLN_OK) (void)hipEventRecord(e1, h->stream);
+    if (rc == QLN_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(QLN_ERR_HIP, "stream synchronize failed");
+    if (rc == QLN_OK && hipEventElapsedTime(ms_total, e0, e1) != hipSuccess) rc = fail(QLN_ERR_HIP, "hipEventElapsedTime failed");
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
 }  // extern "C"

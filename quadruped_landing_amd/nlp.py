@@ -544,6 +544,15 @@ class HybridNLP:
             self._check(vals, self.dims.j_total, "vals"), flags, warmup, iters, ms))
         return np.array(ms[:], dtype=np.float64)
 
+    def time_c_and_jac_total(self, Z, c, vals, warmup: int, iters: int, write_constants: bool = False) -> float:
+        """Elapsed ms of `iters` launches of the fused hot path issued back to back, one pair of HIP events around all of them."""
+        ms = C.c_float()
+        flags = _lib.QLN_JAC_WRITE_CONSTANTS if write_constants else 0
+        _lib.check(_lib.lib().qln_time_constraint_and_jacobian_total(
+            self._h, self._check(Z, self.dims.z_total, "Z"), self._check(c, self.dims.c_total, "c"),
+            self._check(vals, self.dims.j_total, "vals"), flags, warmup, iters, C.byref(ms)))
+        return float(ms.value)
+
     # -- host-pointer (MOI) mode ------------------------------------------------------------------
     def _host_Z(self, Z):
         Z = np.asarray(Z, dtype=np.float64)
