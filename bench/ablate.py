@@ -21,6 +21,8 @@ batch, nlp, Z, c, vals = build(wl, 0, 0, placement_trials=8 if os.environ.get("Q
 f = nlp.new_f(); g = nlp.new_Z()
 print(wl, "fused c+J      : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=False)))
 print(wl, "fused +consts  : %.3f ms" % t_ms(lambda: nlp.eval_c_and_jac(Z, c, vals, write_constants=True)))
+gg = nlp.new_Z()
+print(wl, "eval_all       : %.3f ms" % t_ms(lambda: nlp.eval_all(Z, f, gg, c, vals, write_constants=False)))
 print(wl, "J only         : %.3f ms" % t_ms(lambda: nlp.jac_c(Z, vals, write_constants=False)))
 print(wl, "c only         : %.3f ms" % t_ms(lambda: nlp.eval_c(Z, c)))
 print(wl, "objective      : %.3f ms" % t_ms(lambda: nlp.eval_f(Z, f)))
