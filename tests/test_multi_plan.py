@@ -94,3 +94,37 @@ def test_plan_and_layout_argument_checks_need_no_gpu():
     dims = _lib.QlnDims()
     assert L.qln_layout(C.byref(d), None, None, None) == _lib.QLN_ERR_INVALID_ARGUMENT
     assert L.qln_layout(C.byref(d), C.byref(dims), None, None) == _lib.QLN_OK and dims.c_total > 0
+
+
+def test_shard_plan_property_random_batches():
+    """hypothesis: any batch size, horizon, shard count, alignment and stride -- the plan's offsets tile the gathered constraint
+    vector without overlap, every shard's local offsets are the single-handle layout of its slice, and the whole is a
+    permutation-free concatenation of the shards (problem order preserved)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(B=st.integers(1, 70), N=st.integers(2, 90), n=st.integers(1, 8), align=st.sampled_from([0, 1, 2, 3, 16, 32]),
+           pad=st.integers(0, 7), fmt=st.sampled_from([0, 1]), seed=st.integers(0, 10**6))
+    def check(B, N, n, align, pad, fmt, seed):
+        n = min(n, B)
+        rng = np.random.default_rng(seed)
+        kt, im = rng.integers(1, N + 2, size=B), rng.integers(1, 3, size=B)
+        zs = (20 * N - 5 + pad) if pad else 0
+        d = _desc(B, N, kt, im, z_stride=zs, align=align, fmt=fmt)
+        plans, c_off, c_total = multi.plan(d, n)
+        m_all = 18 * N - kt + 16
+        assert plans[0]["b_begin"] == 0 and plans[-1]["b_end"] == B
+        assert all(plans[r]["b_end"] == plans[r + 1]["b_begin"] for r in range(n - 1))
+        end = 0
+        for p in plans:
+            lo, hi = p["b_begin"], p["b_end"]
+            sd = _desc(hi - lo, N, kt[lo:hi], im[lo:hi], z_stride=zs, align=align, fmt=fmt)
+            dims, loc_c, _ = _layout(sd)
+            assert p["c_displ"] == end and np.array_equal(c_off[lo:hi], end + loc_c)
+            assert (p["z_total"], p["c_total"], p["j_total"]) == (dims.z_total, dims.c_total, dims.j_total)
+            assert p["z_begin"] == lo * (zs or 20 * N - 5)
+            end += dims.c_total
+        assert c_total == end
+        assert np.all(c_off[1:] >= c_off[:-1] + m_all[:-1]) and c_off[-1] + m_all[-1] <= c_total
+
+    check()
