@@ -30,9 +30,6 @@
 #include <cstdlib>
 #endif
 
-#ifndef QLN_OBJ_WAVES
-#define QLN_OBJ_WAVES 8  // waves per workgroup of k_objective_shared
-#endif
 namespace qln {
 
 #ifdef QLN_DIAG
@@ -217,6 +214,26 @@ __device__ __forceinline__ double add_terms_in_order(double J, double term, doub
         for (int i = 0; i < 16; ++i) t[i] = s_term[g + i];
 #pragma unroll
         for (int i = 0; i < 16; ++i) J += t[i];
+    }
+    return J;
+}
+
+// The same sum without LDS, for the one kernel the LDS pipe bounds (k_objective_shared; in the fused kernel and in
+// k_objective the three VALU instructions per term cost more than the broadcast read they replace -- measured, round 3):
+// term i is read out of lane i (two v_readlane_b32 into a scalar pair, the add's operand), eight at a time behind a
+// wave-uniform test -- J + term_0 + ... + term_{n-1} in knot order, n <= 64; lanes past n hold 0.0.
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double add_lane_terms_in_order(double J, double term, int n) {
+#pragma unroll
+    for (int g = 0; g < kWave; g += 8) {
+        if (g < n) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 8; ++i) J += lane_value(term, g + i);
+        }
     }
     return J;
 }
@@ -737,47 +754,79 @@ __global__ __launch_bounds__(kWave) void k_objective(BatchParams P, const double
 }
 
 // The same for the common case of ONE cost table shared by the whole batch (cost_batch == 1) and N <= 64: persistent
-// workgroups of four waves stage the 41 N doubles of the table in LDS once and then walk the batch, one problem per wave
-// at a time -- lane = knot reads its record from LDS (stride 41 doubles: odd, no bank conflicts) instead of issuing 41
-// scattered 8-byte requests per lane to the texture path, which is what bounds k_objective on this workload -- and the next
-// problem's slice of Z is in flight while the current one is summed.
-template <int W>
-__global__ __launch_bounds__(W * kWave) void k_objective_shared(BatchParams P, const double* __restrict__ Z,
-                                                                double* __restrict__ F) {
-    extern __shared__ double s_dyn[];
+// one-wave workgroups walk the batch.  lane = knot is the same knot in every problem, so its 41-double cost record is read
+// ONCE into registers; a problem's slice of Z arrives as 16-byte pieces (the next problem's in flight while this one is
+// summed) and goes through LDS only to turn entry-major into knot-major (a knot's 20 entries 21 doubles apart: lane = knot
+// reads with a stride of 20 doubles would hit 8 of the 64 banks); the in-order sum of the knots' terms is a chain of
+// adds whose operand is read out of the lane that holds it (v_readlane), not 64 LDS broadcasts per lane.  Round 2's
+// version kept the table and the sum in LDS (552 LDS clocks per problem and CU against the 490 that 6.4 KB of Z cost at
+// the HBM peak; this one issues 132), read Z in 8-byte pieces and had one slice in flight: 0.097-0.105 ms = 50-54 % of peak
+// at config 3; this one 0.078-0.081 ms = 64-66 %, what a library reduction over the same bytes reaches
+// (profiles/r03_objective_variants.txt: the sum in LDS, one or three slices in flight, three waves per SIMD are all slower).
+// KI = 16-byte load instructions per slice (ceil((n_nlp - 1) / 128): 1 .. 10), DEPTH = slices in flight per wave,
+// W = waves per SIMD the register budget is sized for; LANESUM = false is the tuning build's LDS-sum variant.
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // a problem's slice is only 8-byte aligned (n_nlp is odd)
+template <int KI, bool LANESUM, int DEPTH, int W>
+__global__ __launch_bounds__(kWave, W) void k_objective_shared(BatchParams P, const double* __restrict__ Z, double* __restrict__ F) {
+    extern __shared__ double s_dyn[];  // [N][21], slack up to the KI * 128 entries the loads cover (+ 64 for the LDS sum)
+    double* s_z = s_dyn;
+    const int lane = threadIdx.x;
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
-    double* s_cost = s_dyn;                                   // [N][41]
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    // a knot's 20 entries sit 21 doubles apart: lane = knot reads with a stride of 20 doubles would hit 8 of the 64 banks
-    const int per_wave = 21 * N + kWave;
-    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * per_wave;  // [N][21]
-    double* s_term = s_z + 21 * N;                               // [64]
-    for (int i = threadIdx.x; i < 41 * N; i += blockDim.x) s_cost[i] = P.cost[i];
-    __syncthreads();
-    constexpr int kIters = 20;
-    const int stride = gridDim.x * W;
-    int b = blockIdx.x * W + wave;
-    double zr[kIters];
-    if (b < P.B) {
+    double* s_term = s_dyn + (KI * 2 * kWave * 21) / 20 + 2;
+    const int npieces = (n_nlp - 1) / 2;  // n_nlp is odd: complete 16-byte pieces, then one double; KI = ceil(npieces / 64)
+    const int kl = min(lane, N - 1);
+    double D[20], d[20];
+    {
+        const double* __restrict__ rec = P.cost + 41 * kl;
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)b * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+        for (int i = 0; i < 20; ++i) {
+            D[i] = rec[i];
+            d[i] = rec[20 + i];
+        }
     }
-    for (; b < P.B; b += stride) {
+    const double c40 = P.cost[41 * kl + 40];
+    const int stride = gridDim.x;
+    // No branch between a request and its use: every load is issued with a clamped address (a wave past the end of the
+    // batch re-reads the last problem, a lane past the end of the slice its last piece), so that the waits the compiler
+    // places count loads (vmcnt(n): the OTHER slot's stay in flight) instead of draining the queue at a block boundary.
+    double2_a8 zr[DEPTH][KI];
+    double ztail[DEPTH];
+    auto request = [&](int bb, int slot) {
+        const double* __restrict__ Zb = Z + (int64_t)min(bb, P.B - 1) * P.z_stride;
+#pragma unroll
+        for (int it = 0; it < KI; ++it)
+            zr[slot][it] = *reinterpret_cast<const double2_a8*>(Zb + 2 * min(it * kWave + lane, npieces - 1));
+        ztail[slot] = Zb[n_nlp - 1];
+    };
+    auto consume = [&](int bb, int slot) {
         wave_lds_sync();  // the previous problem's readers are done
 #pragma unroll
-        for (int it = 0; it < kIters; ++it)
-            if (it * kWave + lane < 20 * N) s_z[it * kWave + lane + (it * kWave + lane) / 20] = zr[it];
-        wave_lds_sync();
-        const int bn = b + stride;  // the next problem's slice, in flight during this one's sums
-        if (bn < P.B) {
-#pragma unroll
-            for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)bn * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
+        for (int it = 0; it < KI; ++it) {  // unpredicated: a lane past the end of the slice writes into the slack behind it
+            const int e = 2 * (it * kWave + lane);
+            s_z[e + e / 20] = zr[slot][it].x;
+            s_z[e + 1 + (e + 1) / 20] = zr[slot][it].y;
         }
-        const int kl = min(lane, N - 1);
-        const double term = objective_term(s_z + 21 * kl, s_cost + 41 * kl, kl < N - 1);
-        const double J = add_terms_in_order(0.0, (lane < N) ? term : 0.0, s_term, lane);
-        if (lane == 0) F[b] = J;
+        s_z[n_nlp - 1 + (n_nlp - 1) / 20] = ztail[slot];  // every lane, the same value: after the slack writes, which reach here
+        wave_lds_sync();
+        request(bb + DEPTH * stride, slot);  // into the registers just emptied
+        const double term = objective_term_regs(s_z + 21 * kl, D, d, c40, kl < N - 1);
+        double J;
+        if constexpr (LANESUM) J = add_lane_terms_in_order(0.0, (lane < N) ? term : 0.0, N);
+        else J = add_terms_in_order(0.0, (lane < N) ? term : 0.0, s_term, lane);
+        if (lane == 0 && bb < P.B) F[bb] = J;
+    };
+    int b = blockIdx.x;
+#pragma unroll
+    for (int sl = 0; sl < DEPTH; ++sl) {
+        // the prologue's requests in the order the loop issues them: the waits inside the loop are placed for both
+        __builtin_amdgcn_sched_barrier(0);
+        request(b + sl * stride, sl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (; b < P.B; b += DEPTH * stride) {
+#pragma unroll
+        for (int sl = 0; sl < DEPTH; ++sl) consume(b + sl * stride, sl);
     }
 }
 
@@ -830,58 +879,86 @@ __global__ __launch_bounds__(256) void k_objective_gradient(BatchParams P, const
     }
 }
 
+// grad_f! for a batch that shares one cost table (cost_batch == 1), N <= 64 (src/costs.jl:26-31; no d(h l)/dh: quirk Q2):
+// persistent one-wave workgroups, the design of k_objective_shared.  A problem's gradient has the layout of its Z, so a
+// lane works on the SAME entries of every problem -- 16-byte piece it * 64 + lane of the slice, whose two entries lie in
+// one knot (20 is even) -- and holds their D and d (Q*x + q / R*u + r: record slots [0, 20) and [20, 40)) in registers for
+// the whole batch.  Only the step lengths h_k go through LDS (the terminal knot's "h" is a 1.0 written once: 1.0 * x == x).
+// Nothing is predicated: a lane past the end of the slice works on the last piece again and stores the same two values to
+// the same address, and a lane whose piece holds no h writes a spare LDS slot -- no block boundary between a request and
+// its use, so the waits count memory operations instead of draining the queue.  Round 2's version (table in LDS, 8-byte
+// pieces, 20 load iterations issued where 13 are needed): 0.164-0.174 ms = 60-64 % of peak at config 3; this one
+// 0.150-0.153 ms = 68-70 % with one slice in flight per wave and 8 waves per CU -- two slices, or 12 / 16 waves per CU with
+// smaller register budgets, change nothing beyond the scatter; three slices are slower (profiles/r03_gradient_variants.txt).
+template <int KI, int DEPTH, int W>
+__global__ __launch_bounds__(kWave, W) void k_objective_gradient_shared(BatchParams P, const double* __restrict__ Z,
+                                                                        double* __restrict__ G) {
+    __shared__ double s_h[kWave + 2];  // h_k, k < N - 1 <= 63; [N - 1] = 1.0; [65] = spare
+    const int lane = threadIdx.x;
+    const int N = P.N;
+    const int n_nlp = 20 * N - 5;
+    const int npieces = (n_nlp - 1) / 2;  // n_nlp is odd: complete 16-byte pieces, then one double (x_N[15]: its own knot's entry 14)
+    double D0[KI], d0[KI], D1[KI], d1[KI];
+    int kk[KI], hs[KI];
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int e = 2 * min(it * kWave + lane, npieces - 1);
+        const int k = e / 20, j = e - 20 * k;
+        const double* __restrict__ rec = P.cost + 41 * k;
+        D0[it] = rec[j], d0[it] = rec[20 + j];
+        D1[it] = rec[j + 1], d1[it] = rec[21 + j];
+        kk[it] = k;
+        hs[it] = (j == 18) ? k : kWave + 1;  // the piece's second entry is u_k[5] = h_k
+    }
+    const double Dt = P.cost[41 * (N - 1) + 14], dt = P.cost[41 * (N - 1) + 34];
+    if (lane == 0) s_h[N - 1] = 1.0;
+    const int stride = gridDim.x;
+    double2_a8 zr[DEPTH][KI];
+    double ztail[DEPTH];
+    auto request = [&](int bb, int slot) {
+        const double* __restrict__ Zb = Z + (int64_t)min(bb, P.B - 1) * P.z_stride;
+#pragma unroll
+        for (int it = 0; it < KI; ++it)
+            zr[slot][it] = *reinterpret_cast<const double2_a8*>(Zb + 2 * min(it * kWave + lane, npieces - 1));
+        ztail[slot] = Zb[n_nlp - 1];
+    };
+    auto consume = [&](int bb, int slot) {
+        wave_lds_sync();  // the previous problem's readers are done
+#pragma unroll
+        for (int it = 0; it < KI; ++it) s_h[hs[it]] = zr[slot][it].y;
+        wave_lds_sync();
+        double* __restrict__ Gb = G + (int64_t)min(bb, P.B - 1) * P.z_stride;
+        double2_a8 out[KI];
+#pragma unroll
+        for (int it = 0; it < KI; ++it) {
+            const double h = s_h[kk[it]];
+            out[it].x = h * (D0[it] * zr[slot][it].x + d0[it]);
+            out[it].y = h * (D1[it] * zr[slot][it].y + d1[it]);
+        }
+        const double gt = Dt * ztail[slot] + dt;
+        request(bb + DEPTH * stride, slot);  // into the registers just emptied
+#pragma unroll
+        for (int it = 0; it < KI; ++it)
+            __builtin_nontemporal_store(out[it], reinterpret_cast<double2_a8*>(Gb + 2 * min(it * kWave + lane, npieces - 1)));
+        Gb[n_nlp - 1] = gt;  // every lane, the same value
+    };
+    int b = blockIdx.x;
+#pragma unroll
+    for (int sl = 0; sl < DEPTH; ++sl) {
+        __builtin_amdgcn_sched_barrier(0);  // the prologue's requests in the order the loop issues them
+        request(b + sl * stride, sl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (; b < P.B; b += DEPTH * stride) {
+#pragma unroll
+        for (int sl = 0; sl < DEPTH; ++sl) consume(b + sl * stride, sl);
+    }
+}
+
 // Initial guess of the reference's notebook (src/main.ipynb:181-198) packed like packZ (src/nlp.jl:94-102),
 // with U = Uref of reference_trajectory (src/ref_traj.jl:19-34): the step BEFORE the hot path, built where the
 // evaluator will read it.  One thread per entry of Z; same operation order as the notebook, so the result is
 // bit-identical to the host generator (quadruped_landing_amd/problem_gen.py).
-// grad_f! for a batch that shares one cost table (cost_batch == 1): persistent four-wave workgroups with the table in LDS,
-// one problem per wave at a time, the next problem's row of Z in flight while this one's gradient is formed.  Only the
-// step lengths h_k go through LDS, so that every entry finds its knot's (src/costs.jl:26-31; no d(h l)/dh: quirk Q2).
-__global__ __launch_bounds__(4 * kWave) void k_objective_gradient_shared(BatchParams P, const double* __restrict__ Z,
-                                                                         double* __restrict__ G) {
-    extern __shared__ double s_dyn[];
-    const int N = P.N;
-    const int n_nlp = 20 * N - 5;
-    double* s_cost = s_dyn;  // [N][41]
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    double* s_z = s_dyn + ((41 * N + 1) & ~1) + wave * kWave;  // the wave's h_k, k < N - 1 <= 63
-    for (int i = threadIdx.x; i < 41 * N; i += blockDim.x) s_cost[i] = P.cost[i];
-    __syncthreads();
-    constexpr int kIters = 20;  // 20 * 64 >= 20 N for N <= 64
-    const int stride = gridDim.x * 4;
-    int b = blockIdx.x * 4 + wave;
-    double zr[kIters];
-    if (b < P.B) {
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)b * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
-    }
-    for (; b < P.B; b += stride) {
-        wave_lds_sync();  // the previous problem's readers are done
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) {  // only the step lengths h_k = u_k[5] are needed by other lanes
-            const int e = it * kWave + lane, k = e / 20;
-            if (e < n_nlp && e - 20 * k == 19) s_z[k] = zr[it];
-        }
-        wave_lds_sync();
-        double* __restrict__ Gb = G + (int64_t)b * P.z_stride;
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int e = it * kWave + lane;
-            if (e < n_nlp) {
-                const int k = e / 20, j = e - 20 * k;
-                const double lin = s_cost[41 * k + j] * zr[it] + s_cost[41 * k + 20 + j];
-                const double gv = (k < N - 1) ? s_z[k] * lin : lin;
-                __builtin_nontemporal_store(gv, &Gb[e]);
-            }
-        }
-        const int bn = b + stride;  // the next problem's row
-        if (bn < P.B) {
-#pragma unroll
-            for (int it = 0; it < kIters; ++it) zr[it] = Z[(int64_t)bn * P.z_stride + min(it * kWave + lane, n_nlp - 1)];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_initial_guess(BatchParams P, double* __restrict__ Z) {
     const int N = P.N;
     const int n_nlp = 20 * N - 5;
@@ -1256,14 +1333,36 @@ hipError_t launch_jacobian_constants(const BatchParams& p, double* vals, hipStre
 
 hipError_t launch_objective(const BatchParams& p, const double* Z, double* f, hipStream_t stream) {
     if (p.cost_batch == 1 && p.N <= kWave && p.B >= 4096) {
-        // one shared cost table: persistent eight-wave workgroups with the table in LDS (two per CU at N = 40)
-        constexpr int W = QLN_OBJ_WAVES;
-        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + W * (21 * p.N + kWave)) * sizeof(double);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16 / W, (size_t)(160 * 1024) / lds));
-        const int grid = std::min(256 * per_cu, (p.B + W - 1) / W);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_shared<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_objective_shared<W>, dim3(grid), dim3(W * kWave), lds, stream, p, Z, f);
+        // one shared cost table: persistent waves with lane = knot's cost record in registers, two per SIMD
+        const int ki_ = ((20 * p.N - 6) / 2 + kWave - 1) / kWave;
+        const size_t lds = (size_t)((ki_ * 2 * kWave * 21) / 20 + 2 + kWave) * sizeof(double);
+        const int ki = ((20 * p.N - 6) / 2 + kWave - 1) / kWave;  // 16-byte load instructions per slice: 1 .. 10
+        int per_cu = 8;
+#ifdef QLN_TUNING
+        static const int var = [] { const char* e = getenv("QLN_OBJ_VARIANT"); return e ? atoi(e) : 0; }();
+        static const int pc = [] { const char* e = getenv("QLN_OBJ_PER_CU"); return e ? atoi(e) : 0; }();
+        if (pc) per_cu = pc;
+        const int g_ = std::min(256 * per_cu, p.B);
+#define OBJ_LAUNCH(...) hipLaunchKernelGGL((k_objective_shared<__VA_ARGS__>), dim3(g_), dim3(kWave), lds, stream, p, Z, f); return hipGetLastError()
+        if (ki == 7) {
+            switch (var) {
+                case 1: OBJ_LAUNCH(7, false, 2, 2);
+                case 2: OBJ_LAUNCH(7, true, 1, 2);
+                case 3: OBJ_LAUNCH(7, true, 1, 3);
+                case 4: OBJ_LAUNCH(7, false, 1, 3);
+                case 5: OBJ_LAUNCH(7, true, 3, 2);
+                default: break;
+            }
+        }
+#endif
+        const int grid = std::min(256 * per_cu, p.B);
+#define OBJ_CASE(K) case K: hipLaunchKernelGGL((k_objective_shared<K, true, 2, 2>), dim3(grid), dim3(kWave), lds, stream, p, Z, f); break
+        switch (ki) {
+            OBJ_CASE(1); OBJ_CASE(2); OBJ_CASE(3); OBJ_CASE(4); OBJ_CASE(5);
+            OBJ_CASE(6); OBJ_CASE(7); OBJ_CASE(8); OBJ_CASE(9); OBJ_CASE(10);
+            default: return hipErrorInvalidValue;
+        }
+#undef OBJ_CASE
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_objective, dim3(xcd_grid(p.B)), dim3(kWave), 0, stream, p, Z, f);
@@ -1291,12 +1390,33 @@ hipError_t launch_initial_guess(const BatchParams& p, double* Z, hipStream_t str
 
 hipError_t launch_objective_gradient(const BatchParams& p, const double* Z, double* grad, hipStream_t stream) {
     if (p.cost_batch == 1 && p.N <= kWave && p.B >= 4096) {
-        const size_t lds = (size_t)(((41 * p.N + 1) & ~1) + 4 * kWave) * sizeof(double);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
-        const int grid = std::min(256 * per_cu, (p.B + 3) / 4);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_objective_gradient_shared), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_objective_gradient_shared, dim3(grid), dim3(4 * kWave), lds, stream, p, Z, grad);
+        const int ki = ((20 * p.N - 6) / 2 + kWave - 1) / kWave;  // 16-byte pieces per lane and slice: 1 .. 10
+        int per_cu = 8;
+#ifdef QLN_TUNING
+        static const int var = [] { const char* e = getenv("QLN_GRAD_VARIANT"); return e ? atoi(e) : 0; }();
+        static const int pc = [] { const char* e = getenv("QLN_GRAD_PER_CU"); return e ? atoi(e) : 0; }();
+        if (pc) per_cu = pc;
+        const int g_ = std::min(256 * per_cu, p.B);
+#define GRAD_LAUNCH(...) hipLaunchKernelGGL((k_objective_gradient_shared<__VA_ARGS__>), dim3(g_), dim3(kWave), 0, stream, p, Z, grad); return hipGetLastError()
+        if (ki == 7) {
+            switch (var) {
+                case 1: GRAD_LAUNCH(7, 2, 2);
+                case 2: GRAD_LAUNCH(7, 2, 3);
+                case 3: GRAD_LAUNCH(7, 1, 3);
+                case 4: GRAD_LAUNCH(7, 3, 2);
+                case 5: GRAD_LAUNCH(7, 1, 4);
+                default: break;
+            }
+        }
+#endif
+        const int grid = std::min(256 * per_cu, p.B);
+#define GRAD_CASE(K) case K: hipLaunchKernelGGL((k_objective_gradient_shared<K, 1, 2>), dim3(grid), dim3(kWave), 0, stream, p, Z, grad); break
+        switch (ki) {
+            GRAD_CASE(1); GRAD_CASE(2); GRAD_CASE(3); GRAD_CASE(4); GRAD_CASE(5);
+            GRAD_CASE(6); GRAD_CASE(7); GRAD_CASE(8); GRAD_CASE(9); GRAD_CASE(10);
+            default: return hipErrorInvalidValue;
+        }
+#undef GRAD_CASE
         return hipGetLastError();
     }
     const int64_t total = (int64_t)p.B * (20 * p.N - 5);

@@ -507,17 +507,25 @@ def test_eval_all_gives_the_bits_of_the_separate_entry_points(B, N, ragged, fmt)
     assert np.array_equal(f.cpu().numpy(), ref["f"])  # and the objective is bit-identical to the oracle
 
 
-@pytest.mark.parametrize("N,kt,im", [(64, 20, 1), (63, 33, 2), (2, 2, 1), (17, 6, 1)])
-def test_shared_cost_table_kernels_at_their_size_limits(N, kt, im):
+@pytest.mark.parametrize("N,kt,im,z_pad", [(64, 20, 1, 0), (63, 33, 2, 0), (2, 2, 1, 0), (17, 6, 1, 0),
+                                            # one horizon per number of 16-byte load instructions a slice of Z takes (1 .. 10)
+                                            (6, 3, 1, 0), (7, 3, 2, 0), (14, 5, 1, 0), (20, 7, 1, 0), (26, 9, 2, 0), (33, 12, 1, 0),
+                                            (39, 14, 1, 0), (45, 20, 1, 0), (46, 20, 2, 0), (52, 30, 1, 0), (58, 10, 1, 0),
+                                            # slices 16-byte aligned (even stride) and with a gap between problems
+                                            (40, 14, 1, 1), (40, 14, 2, 6)])
+def test_shared_cost_table_kernels_at_their_size_limits(N, kt, im, z_pad):
     """A batch of >= 4 096 problems that shares one cost table runs eval_f / grad_f! through the shared-table kernels
-    (k_objective_shared, k_objective_gradient_shared: table in LDS, persistent workgroups) for N <= 64: objective and
-    gradient of EVERY problem bit-identical to the oracle at the horizon limits of those kernels."""
+    (k_objective_shared: persistent waves, lane = knot's cost record in registers, a problem's slice of Z as 16-byte pieces
+    that are only 8-byte aligned when the stride is odd; k_objective_gradient_shared: table in LDS) for N <= 64: objective
+    and gradient of EVERY problem bit-identical to the oracle at every instantiation of those kernels, for a batch size
+    that leaves the persistent waves' last round partly empty."""
     import torch
     from quadruped_landing_amd import HybridNLP, problem_gen as PG
 
     B = 4096 + 3
     batch = PG.make_batch(B, N, kt, im, seed=N)
-    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                    z_stride=(20 * N - 5 + z_pad) if z_pad else 0)
     Z = nlp.upload_Z(batch.Z)
     f, g = nlp.eval_f(Z), nlp.grad_f(Z)
     torch.cuda.synchronize()
