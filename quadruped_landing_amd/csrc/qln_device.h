@@ -123,6 +123,10 @@ __host__ __device__ constexpr int step_block_offset(int k, int N, int k_trans) {
 
 // internal launch flag (bit 0 is QLN_JAC_WRITE_CONSTANTS): prefer latency over throughput for a small batch
 constexpr uint32_t kLaunchSplit = 2u;
+// L2 prefetch for a later workgroup of the XCD (k_constraint_jacobian): distance in problems in bits 8..28 of the flags (0 = off),
+// what is prefetched in bits 29..31 (default: the slice of Z only)
+constexpr uint32_t kDensePrefetchAhead = 64;
+constexpr uint32_t kPrefetchNoZ = 1u << 29, kPrefetchBnd = 1u << 30, kPrefetchDesc = 1u << 31;
 
 // Fused eval_c! + jac_c! over problems [b_begin, b_begin + nb).  c or vals may be null.
 hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c,

@@ -26,7 +26,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#ifdef QLN_TUNING
+#if defined(QLN_TUNING) || defined(QLN_PREFETCH_KNOB)
 #include <cstdlib>
 #endif
 
@@ -367,6 +367,38 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     // length of the step-block section of vals
     const int dyn_blocks = NNZ ? step_block_offset(N - 1, N, kt) : kBlk * (N - 1);
     double J_obj = 0.0;  // WITH_F: eval_f accumulated over the chunks, in knot order
+    // L2 prefetch for a LATER workgroup of this XCD (flags >> 8 = how many problems ahead on the XCD; 0 = off): one 4-byte load
+    // per 64 bytes of that problem's slice, issued once this wave's own slice has arrived (loads return in order: a wait
+    // for something requested after them would wait for them too) and never read -- their only "use" is a never-true test at
+    // the very end of the kernel, where the hardware waits for every outstanding memory operation anyway (s_endpgm).  The
+    // workgroup that is dispatched to the slot this or a neighbouring wave frees then finds its slice in the XCD's L2 instead
+    // of paying an HBM round trip under a write-saturated memory system before it can start.  Four loads cover 16 KB of slice
+    // (N <= 102; longer slices are prefetched in part), addresses clamped.
+    int pf_acc[5] = {0, 0, 0, 0, 0};
+    auto prefetch_later_workgroup = [&]() {
+        if constexpr (!SPLIT) {
+            const int ahead = (int)((flags >> 8) & 0x1fffffu);
+            const int per_xcd = (nb + 7) >> 3;
+            const int local = (int)(blockIdx.x >> 3) + ahead;
+            const int vn = (int)(blockIdx.x & 7) * per_xcd + local;
+            if (ahead > 0 && local < per_xcd && vn < nb) {  // wave-uniform
+                if (!(flags & kPrefetchNoZ)) {
+                    const char* Zn = reinterpret_cast<const char*>(Z + (int64_t)(b_begin + vn) * P.z_stride);
+                    const int bytes = (20 * N - 5) * 8;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf_acc[i] = *reinterpret_cast<const int*>(Zn + min(i * 4096 + lane * 64, bytes - 4));
+                }
+                if (flags & (kPrefetchBnd | kPrefetchDesc)) {  // that problem's boundary vectors (240 B) and / or descriptor (32 B)
+                    const char* bn = reinterpret_cast<const char*>(P.bnd + (int64_t)(b_begin + vn) * 30);
+                    const char* dn = reinterpret_cast<const char*>(P.desc + (b_begin + vn));
+                    const bool both = (flags & kPrefetchBnd) && (flags & kPrefetchDesc);
+                    const char* a = (flags & kPrefetchBnd) ? bn + min(lane * 64, 236) : dn;
+                    if (both && lane >= 4) a = dn;
+                    pf_acc[4] = *reinterpret_cast<const int*>(a);
+                }
+            }
+        }
+    };
 
     if (WITH_J && (flags & 1u) && kc_begin == 0) {
         // constant entries of jac_c! (src/constraints.jl:228-229, :200, :235-265)
@@ -444,6 +476,7 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
                     if (lane == 29) c_put(o_fc, s_z[20 * (nk - 1) + 16] + s_z[20 * (nk - 1) + 18] + mb * g);
                 }
             }
+            if (kc0 == kc_begin) prefetch_later_workgroup();  // the wave's own first slice (and bnd) have arrived
         }
 
         QLN_STAMP(1);
@@ -689,6 +722,13 @@ __global__ __launch_bounds__(kWave, W) void k_constraint_jacobian(BatchParams P,
     }
     if constexpr (WITH_F) {
         if (lane == 0) F[b] = J_obj;
+    }
+    if constexpr (!SPLIT) {
+        // the prefetch loads' only reader (see above): never true (N >= 2), placed where the wave has nothing left to do
+        if (N < 0 && (pf_acc[0] | pf_acc[1] | pf_acc[2] | pf_acc[3] | pf_acc[4]) == 0x5eedbeef) {
+            if (WITH_C) Cb[0] = 0.0;
+            else Vb[0] = 0.0;
+        }
     }
     QLN_STAMP(15);
 }
@@ -1152,9 +1192,27 @@ inline void apply_floor_mode() {
 }
 #endif
 
+// bits 8.. of the kernel's flags: how many problems ahead on its XCD a workgroup prefetches into L2 (0 = off).  The knob
+// builds (make tuning / prefetchknob) let QLN_PREFETCH_AHEAD override the caller's choice (bench/prefetch_ahead.py).
+inline uint32_t prefetch_flags(uint32_t ahead_default, uint32_t what_default = 0u) {
+#if defined(QLN_TUNING) || defined(QLN_PREFETCH_KNOB)
+    static const int ahead = [] {
+        const char* e = getenv("QLN_PREFETCH_AHEAD");
+        return e ? atoi(e) : -1;
+    }();
+    static const int mask = [] {  // QLN_PREFETCH_MASK: 1 = slice of Z, 2 = boundary vectors, 4 = descriptor
+        const char* e = getenv("QLN_PREFETCH_MASK");
+        return e ? atoi(e) : -1;
+    }();
+    if (ahead >= 0) ahead_default = (uint32_t)ahead;
+    if (mask >= 0) what_default = ((mask & 1) ? 0u : kPrefetchNoZ) | ((mask & 2) ? kPrefetchBnd : 0u) | ((mask & 4) ? kPrefetchDesc : 0u);
+#endif
+    return (ahead_default << 8) | what_default;
+}
+
 template <int T, int KC, int W, bool NNZ = false, bool SPLIT = false>
 hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, double* vals,
-                       uint32_t flags, hipStream_t stream) {
+                       uint32_t flags, hipStream_t stream, uint32_t prefetch_ahead = 0) {
     dim3 grid(xcd_grid(SPLIT ? nb * ((p.N - 2) / KC + 1) : nb)), block(kWave);
 #ifdef QLN_TUNING
     apply_floor_mode();
@@ -1166,6 +1224,7 @@ hipError_t launch_cj_t(const BatchParams& p, int32_t b_begin, int32_t nb, const 
 #else
     constexpr unsigned pad = 0;
 #endif
+    if (!SPLIT) flags = (flags & 0xffu) | prefetch_flags(prefetch_ahead);
     // outputs larger than the caches are streamed (non-temporal stores); small ones stay cacheable
     const bool stream_out = (int64_t)nb * (p.N - 1) * (NNZ ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
     auto go = [&](auto with_c, auto with_j, auto streamed) {
@@ -1187,8 +1246,8 @@ template <int T, int KC, int W>
 hipError_t launch_c_only_t(const BatchParams& p, int32_t b_begin, int32_t nb, const double* Z, double* c, hipStream_t stream) {
     dim3 grid(xcd_grid(nb)), block(kWave);
     const bool stream_out = (int64_t)nb * (18 * p.N + 16) * 8 > ((int64_t)512 << 20);
-    if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, true>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, 0u);
-    else hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, false>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, 0u);
+    if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, true>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, prefetch_flags(0));
+    else hipLaunchKernelGGL((k_constraint_jacobian<T, KC, W, true, false, false, false, false>), grid, block, 0, stream, p, b_begin, nb, Z, c, nullptr, prefetch_flags(0));
     return hipGetLastError();
 }
 
@@ -1273,7 +1332,10 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
     // dense blocks: a 12-block tile (28.8 KB, 5 waves per CU).  All three tile sizes sit on the launch's floor (profiles/r03_dense_floor.txt);
     // on region-placed buffers T = 12 is the fastest by 0.5-1 % (config 3: 1.060-1.063 against 1.069-1.074 ms for T = 16, config 4:
     // 2.155-2.162 against 2.168-2.174 ms; round 1 chose T = 16 on buffers lying in one region)
-    return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+    // One-chunk problems (N <= 65) prefetch the slice of the workgroup 64 problems ahead on the XCD into L2 (kDensePrefetchAhead):
+    // config 3 1.056-1.068 -> 1.031-1.040 ms for every distance from 16 to 1024, same box (profiles/r03_prefetch_ahead.txt);
+    // two-chunk problems (config 4), the structural format and the constraint-only launch do not gain and stay without.
+    return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 64) ? kDensePrefetchAhead : 0u);
 }
 
 // f, grad, c and the Jacobian values of the whole batch from ONE read of Z (qln_eval_all)
@@ -1283,7 +1345,11 @@ hipError_t launch_eval_all(const BatchParams& p, const double* Z, double* f, dou
     dim3 grid(xcd_grid(nb)), block(kWave);
     const bool structural = p.jac_format == QLN_JAC_FORMAT_STRUCTURAL;
     const bool stream_out = (int64_t)nb * (p.N - 1) * (structural ? 71 : kBlk) * 8 > ((int64_t)512 << 20);
-    flags &= QLN_JAC_WRITE_CONSTANTS;
+    // dense one-chunk problems prefetch like the fused launch, and the later problem's boundary vectors and descriptor with the
+    // slice: 1.18-1.20 -> 1.11-1.15 ms at config 3 (the slice alone: 1.16-1.19; for the fused launch WITHOUT the objective the two
+    // extras cost what the slice gains -- profiles/r03_prefetch_ahead.txt)
+    flags = (flags & QLN_JAC_WRITE_CONSTANTS) |
+            ((!structural && p.N - 1 <= 64) ? prefetch_flags(kDensePrefetchAhead, kPrefetchBnd | kPrefetchDesc) : prefetch_flags(0));
     if (structural) {
         const unsigned lds = (unsigned)nnz_lds_bytes(p, 40, 40, true);
         if (stream_out) hipLaunchKernelGGL((k_constraint_jacobian<0, 40, 1, true, true, true, false, true, true>), grid, block, lds, stream, p, 0, nb, Z, c, vals, flags, f, grad);
