@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <exception>
 #include <cstring>
 #include <thread>
 #include <new>
@@ -539,7 +540,15 @@ int qln_multi_time_constraint_and_jacobian(qln_multi* m, int32_t warmup, int32_t
         go = false;
         std::vector<std::thread> th;
         th.reserve(n);
-        for (size_t r = 0; r < n; ++r) th.emplace_back(worker, r, times, timed);
+        // nothing may throw across the C ABI: a thread that cannot be started (std::system_error) releases the ones that
+        // were, waits for them and becomes an error code
+        try {
+            for (size_t r = 0; r < n; ++r) th.emplace_back(worker, r, times, timed);
+        } catch (const std::exception& e) {
+            go.store(true, std::memory_order_release);
+            for (auto& t : th) t.join();
+            return fail(QLN_ERR_HIP, std::string("qln_multi_time_constraint_and_jacobian: could not start an issue thread: ") + e.what());
+        }
         while (ready.load() < (int)n) std::this_thread::yield();
         const auto t0 = std::chrono::steady_clock::now();
         go.store(true, std::memory_order_release);
