@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-8  # north_star: "within 1e-8 relative on FP64 dynamics/Jacobian entries"
 
 
+def _fuzz_examples(default):
+    """hypothesis examples per property test: the suite's default, or QLN_FUZZ_EXAMPLES for a one-off campaign on the GPU box"""
+    import os
+
+    return int(os.environ.get("QLN_FUZZ_EXAMPLES", default))
+
+
 def _gpu_eval(batch, **kw):
     import torch
     from quadruped_landing_amd import HybridNLP
@@ -363,7 +370,7 @@ def test_random_shapes_and_layouts_property():
     from hypothesis import given, settings, strategies as st
     from quadruped_landing_amd import problem_gen as PG
 
-    @settings(max_examples=20, deadline=None)
+    @settings(max_examples=_fuzz_examples(20), deadline=None)
     @given(B=st.integers(1, 40), N=st.integers(2, 150), pad=st.integers(0, 9), align=st.sampled_from([1, 2, 3, 16, 32]),
            seed=st.integers(0, 10**6))
     def check(B, N, pad, align, seed):
@@ -372,6 +379,56 @@ def test_random_shapes_and_layouts_property():
         _compare(batch, *out)
 
     check()
+
+
+def test_every_entry_point_gives_the_same_bits_property():
+    """Randomised (hypothesis): for any B (incl. more problems than one round of the chip's XCD map, B % 8 != 0), N (one to
+    three chunks), ragged descriptors, format, Z stride and alignment, every way of asking for a quantity -- the fused launch,
+    the constraint-only and Jacobian-only launches, qln_eval_all, qln_eval_objective_and_constraint, the separate objective /
+    gradient kernels -- returns the same bits, NaN padding untouched; the fused launch itself is held to the oracle."""
+    import torch
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    ran = [0, 0]
+
+    @settings(max_examples=_fuzz_examples(12), deadline=None)
+    @given(B=st.one_of(st.integers(1, 60), st.integers(250, 700)), N=st.integers(2, 140), pad=st.integers(0, 5),
+           align=st.sampled_from([1, 2, 16]), fmt=st.sampled_from(["dense_blocks", "structural"]), shared=st.booleans(),
+           seed=st.integers(0, 10**6))
+    def check(B, N, pad, align, fmt, shared, seed):
+        ran[0] += 1
+        ran[1] += B * N
+        if N > 3:
+            batch = PG.make_batch(B, N, seed=seed, ragged=not shared, **({"k_trans": min(14, N), "init_mode": 1 + seed % 2} if shared else {}))
+        else:
+            batch = PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf,
+                        z_stride=(20 * N - 5 + pad) if pad else 0, align=align, jac_format=fmt)
+        Z = nlp.upload_Z(batch.Z)
+        nan = float("nan")
+        mk = lambda n: torch.full((n,), nan, dtype=torch.float64, device="cuda")
+        zt, ct, jt = nlp.dims.z_total, nlp.dims.c_total, nlp.dims.j_total
+        c0, v0 = nlp.eval_c_and_jac(Z, mk(ct), mk(jt))
+        c1 = nlp.eval_c(Z, mk(ct))
+        v1 = nlp.jac_c(Z, mk(jt))
+        f2, g2, c2, v2 = nlp.eval_all(Z, mk(B), mk(zt), mk(ct), mk(jt))
+        f3, c3 = nlp.eval_f_and_c(Z, mk(B), mk(ct))
+        f4, g4 = nlp.eval_f(Z), nlp.grad_f(Z, mk(zt))
+        torch.cuda.synchronize()
+        eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+        assert eq(c0, c1) and eq(c0, c2) and eq(c0, c3), "constraint vector differs between entry points"
+        assert eq(v0, v1) and eq(v0, v2), "Jacobian values differ between entry points"
+        assert eq(f2, f3) and eq(f2, f4) and eq(g2, g4), "objective / gradient differ between entry points"
+        if fmt == "dense_blocks" and B <= 60:
+            _compare(batch, nlp, c0.cpu().numpy(), v0.cpu().numpy(), f4.cpu().numpy(), g4.cpu().numpy())
+        else:
+            ref = oracle_batch(batch, nlp, want_c=True, want_j=False, want_f=True, want_grad=False)
+            assert np.array_equal(f4.cpu().numpy(), ref["f"])
+            assert np.array_equal(np.isnan(c0.cpu().numpy()), np.isnan(ref["c"])) and rel_err(c0.cpu().numpy(), ref["c"], floor=1.0) <= RTOL
+
+    check()
+    print(f"{ran[0]} examples, {ran[1]} knot points")
 
 
 def test_dense_host_jacobian_of_any_problem_in_a_batch_and_two_handles():
