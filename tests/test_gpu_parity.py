@@ -431,6 +431,50 @@ def test_every_entry_point_gives_the_same_bits_property():
     print(f"{ran[0]} examples, {ran[1]} knot points")
 
 
+def test_extreme_magnitudes_value_path_property():
+    """Randomised (hypothesis): decision vectors whose entries span the whole FP64 range -- denormals, 1e+-300, exact zeros of
+    either sign, negative step lengths, intermediate overflow to Inf and Inf - Inf = NaN.  The value path follows the
+    reference's operation order with IEEE division and no contraction, so the equality rows of c, the objective and the
+    gradient must equal the oracle's BIT FOR BIT, NaN for NaN and Inf for Inf; the clearance rows differ by at most 1 ulp
+    (device sin vs libm, huge arguments included).  (Jacobian entries are not compared here: closed form and dual numbers
+    overflow and cancel at different places; the launch must merely survive.)"""
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import problem_gen as PG
+
+    ran = [0]
+
+    @settings(max_examples=_fuzz_examples(10), deadline=None)
+    @given(B=st.integers(1, 24), N=st.integers(2, 90), fmt=st.sampled_from(["dense_blocks", "structural"]),
+           frac=st.sampled_from([0.002, 0.02, 0.3, 1.0]), lo=st.sampled_from([-320, -300, -30]), hi=st.sampled_from([30, 150, 300]),
+           seed=st.integers(0, 10**6))
+    def check(B, N, fmt, frac, lo, hi, seed):
+        ran[0] += 1
+        batch = PG.make_batch(B, N, seed=seed, ragged=True) if N > 3 else PG.make_batch(B, N, 2, 1 + seed % 2, seed=seed)
+        rng = np.random.default_rng(seed + 1)
+        Z = batch.Z
+        hit = rng.random(Z.shape) < frac
+        mag = 10.0 ** rng.uniform(lo, hi, size=Z.shape)          # 1e-320 is denormal
+        mag[rng.random(Z.shape) < 0.1] = 0.0
+        Z[hit] = (np.where(rng.random(Z.shape) < 0.5, -1.0, 1.0) * mag)[hit]
+        with np.errstate(all="ignore"):
+            nlp, c, v, f, g = _gpu_eval(batch, jac_format=fmt)
+            ref = oracle_batch(batch, nlp, want_c=True, want_j=False, want_f=True, want_grad=True)
+        same = lambda a, b: np.array_equal(a, b, equal_nan=True)
+        for b in range(B):
+            neq = nlp.cinds(b)[5][1]  # the equality rows come first; the clearance rows (device sin) are the last group
+            a, r = nlp.split_c(c, b), nlp.split_c(ref["c"], b)
+            assert same(a[:neq], r[:neq]), f"equality rows differ (problem {b})"
+            ai, ri = a[neq:], r[neq:]
+            assert np.array_equal(np.isnan(ai), np.isnan(ri))
+            ok = np.isfinite(ri)
+            assert same(ai[~ok], ri[~ok]) and np.all(np.abs(ai[ok] - ri[ok]) <= 2.3e-16 * np.maximum(np.abs(ri[ok]), 0.25))
+        assert same(f, ref["f"]), "objective differs"
+        assert same(g.reshape(B, -1)[:, : nlp.n_nlp], ref["grad"].reshape(B, -1)[:, : nlp.n_nlp]), "gradient differs"
+
+    check()
+    print(f"{ran[0]} examples")
+
+
 def test_dense_host_jacobian_of_any_problem_in_a_batch_and_two_handles():
     """MOI dense mode addresses one problem of a batch; two handles on the same device do not interfere."""
     from oracle import oracle as O
