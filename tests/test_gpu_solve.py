@@ -379,3 +379,54 @@ def test_warm_start_from_the_references_other_trajectories_feasibility_only(gold
     assert drift <= 4e-4
     assert inf[5] == 0 and viol[0] <= 1e-6 * 1.0001 and bviol[0] <= 1e-6
     assert np.all(np.isfinite(Zh))
+
+
+def test_solver_invariants_for_random_shapes_property():
+    """Randomised (hypothesis): any horizon (2-130), ragged transition knots / contact modes, batch size, guess noise.  Whatever
+    the status, (i) the solve terminates with a finite trajectory and a status in {0, 1, 2}; (ii) the returned states are the
+    evaluator's RK4 roll-out of the returned controls from x0 -- initial-condition, dynamics and contact-init rows of
+    qln_eval_constraint are exactly 0.0; (iii) the report is the evaluator's: info[2] = qln_eval_objective bit for bit,
+    info[3] >= qln_constraint_violation (it adds solve()'s variable bounds); (iv) status 0 means what the header says:
+    violation <= tol; (v) the same problem solved alone gives the same bits (no dependence on batch position)."""
+    import os
+    import torch
+    from hypothesis import given, settings, strategies as st
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    ran = [0, 0]
+
+    @settings(max_examples=int(os.environ.get("QLN_FUZZ_EXAMPLES", 8)), deadline=None)
+    @given(B=st.integers(1, 12), N=st.integers(2, 130), ragged=st.booleans(), noise=st.sampled_from([0.0, 0.01, 0.05]),
+           seed=st.integers(0, 10**6))
+    def check(B, N, ragged, noise, seed):
+        ran[0] += 1
+        if N > 3 and ragged:
+            batch = PG.make_batch(B, N, seed=seed, ragged=True, noise=noise, dt=0.009 * 40 / N)
+        else:
+            batch = PG.make_batch(B, N, max(2, min(N, N // 3 + 1)), 1 + seed % 2, seed=seed, noise=noise, dt=0.009 * 40 / N)
+        nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf)
+        Z0 = nlp.upload_Z(batch.Z)
+        Z, info = nlp.solve(Z0.clone())
+        torch.cuda.synchronize()
+        inf = info.cpu().numpy()
+        viol, f, bviol, c, Zh = _judge(nlp, Z)
+        assert np.all(np.isfinite(Zh)) and np.all(np.isfinite(f)) and np.all(np.isin(inf[:, 5], (0, 1, 2)))
+        assert np.array_equal(inf[:, 2], f), "reported objective is not the evaluator's"
+        assert np.all(inf[:, 3] >= viol) and np.all(inf[:, 3] <= np.maximum(viol, bviol) * (1 + 1e-12) + 1e-300)
+        ok = inf[:, 5] == 0
+        ran[1] += int(ok.sum())
+        assert np.all(inf[ok, 3] <= 1e-6 * 1.0001)
+        for b in range(B):
+            ci = nlp.cinds(b)
+            seg = nlp.split_c(c, b)
+            assert np.all(seg[:15] == 0.0) and np.all(seg[ci[2][0] - 1 : ci[2][1]] == 0.0)
+        # batch-position independence: the last problem alone
+        b = B - 1
+        one = HybridNLP(batch.model, batch.obj if batch.obj.ndim == 2 else batch.obj[b : b + 1], batch.init_mode[b : b + 1],
+                        batch.k_trans[b : b + 1], batch.N, batch.x0[b : b + 1], batch.xf[b : b + 1])
+        Z1, info1 = one.solve(one.upload_Z(batch.Z[b : b + 1]))
+        torch.cuda.synchronize()
+        assert torch.equal(Z1.view(-1)[: nlp.n_nlp], Z.view(B, -1)[b, : nlp.n_nlp]) and torch.equal(info1[0, :10], info[b, :10])
+
+    check()
+    print(f"{ran[0]} examples, {ran[1]} problems solved to tolerance")
