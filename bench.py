@@ -361,8 +361,13 @@ def run_single_process(args):
     from quadruped_landing_amd import PlanarQuadruped, multi, problem_gen as PG
 
     n = args.gpus
-    if torch.cuda.device_count() < n:
+    # rehearsal of the N > 1 control flow of this driver on a one-GPU box (tests / profiles only): n shards on device 0
+    # (qln_multi_create_on_one_device: the gather's exchange is device copies, RCCL admits one rank per device) -- the line
+    # says so and its value is NOT a multi-GPU number
+    rehearse = os.environ.get("QLN_BENCH_REHEARSE_ON_DEVICE0") == "1"
+    if torch.cuda.device_count() < n and not rehearse:
         raise SystemExit(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible")
+    devs = dict(devices=[0] * n, one_device=True) if rehearse else dict(devices=list(range(n)))
     w = WORKLOADS[args.workload]
     B, N = w["B"], w["N"]
     device_data = not (w["ragged"] or args.host_data)
@@ -371,7 +376,7 @@ def run_single_process(args):
         kt = np.full(B * n, w["k_trans"], dtype=np.int32)
         im = np.full(B * n, 1, dtype=np.int32)
         xf = np.tile(PG.terminal_state(model), (B * n, 1))
-        m = multi.MultiNLP(model, None, im, kt, N, np.zeros((B * n, 15)), xf, devices=list(range(n)), jac_format=args.jac_format)
+        m = multi.MultiNLP(model, None, im, kt, N, np.zeros((B * n, 15)), xf, jac_format=args.jac_format, **devs)
         m.sample_drop_states([PG.drop_state_sampler(r, model) for r in range(n)])  # shard r = rank r's workload (seed r)
         m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=False)
         m.initial_guess()
@@ -381,8 +386,7 @@ def run_single_process(args):
     else:
         shards = [PG.make_batch(B, N, w["k_trans"] or 14, 1, seed=r, ragged=w["ragged"], build_obj=False) for r in range(n)]
         cat = lambda name: np.concatenate([getattr(b, name) for b in shards])
-        m = multi.MultiNLP(model, None, cat("init_mode"), cat("k_trans"), N, cat("x0"), cat("xf"),
-                           devices=list(range(n)), jac_format=args.jac_format)
+        m = multi.MultiNLP(model, None, cat("init_mode"), cat("k_trans"), N, cat("x0"), cat("xf"), jac_format=args.jac_format, **devs)
         m.set_lqr_cost(PG.Q_DIAG, PG.R_DIAG, PG.Q_DIAG, 0.009, per_problem=w["ragged"])
         m.set_Z(cat("Z"))
         shard0 = shards[0]
@@ -415,7 +419,9 @@ def run_single_process(args):
     t_gather_c = time.perf_counter() - tg
     total_B = B * n
     out = base_record(args, total_B * N * K / elapsed, n, elapsed, B, N, m.z_stride,
-                      {"driver": "one process, one issue thread per device, qln_multi_* (include/qln_multi.h)",
+                      {"driver": "one process, one issue thread per device, qln_multi_* (include/qln_multi.h)"
+                                 + (f"; REHEARSAL: all {n} shards on device 0 (qln_multi_create_on_one_device, gather by device copies) -- "
+                                    "control flow only, not a multi-GPU measurement" if rehearse else ""),
                        "jacobian_buffer": "qln_vals_alloc_placed per device" if args.placement_trials > 1 else "plain allocation",
                        "workload_data": data_how, "timing": tail_note(),
                        "multi_gpu_status": multi_gpu_status(n)})

@@ -93,6 +93,11 @@ int qln_multi_plan(const qln_batch_desc* desc, int n_devices, qln_shard_plan* pl
  * (`devices` = their ordinals, NULL = 0 .. n_devices-1), creates one evaluator handle + stream + buffer set per
  * device and the RCCL clique.  A per-problem cost table (cost_batch == B) is sharded like the problems. */
 int qln_multi_create(const qln_batch_desc* desc, int n_devices, const int* devices, qln_multi** out);
+/* REHEARSAL of the n > 1 paths on a box with one GPU: the same sharding, handles, streams, issue threads, buffers and gather
+ * offsets with all `n_shards` shards on ONE device.  RCCL admits one rank per device, so no clique is created and the gather's
+ * send / receive pairs are device copies on the root's stream ordered behind the sending shard's stream (what the pairs are
+ * over RCCL).  Everything else of this header behaves as after qln_multi_create.  Not a way to run faster. */
+int qln_multi_create_on_one_device(const qln_batch_desc* desc, int n_shards, int device, qln_multi** out);
 int qln_multi_destroy(qln_multi* m);
 int qln_multi_num_devices(const qln_multi* m, int* n_devices);
 /* shard r: its device, its range of the global problem index, its evaluator handle (owned by m; every single-GPU entry

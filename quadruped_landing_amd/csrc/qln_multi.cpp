@@ -68,6 +68,7 @@ struct qln_multi {
     int root = -1;
     double *g_f = nullptr, *g_viol = nullptr, *g_c = nullptr;
     uint32_t gathered = 0;
+    bool one_device = false;  // qln_multi_create_on_one_device: no RCCL clique, the gather's exchange is device copies
 };
 
 extern "C" {
@@ -266,7 +267,7 @@ int qln_multi_plan(const qln_batch_desc* d, int n, qln_shard_plan* plan, int64_t
     return QLN_OK;
 }
 
-int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_multi** out) {
+static int multi_create_impl(const qln_batch_desc* d, int n, const int* devices, bool one_device, qln_multi** out) {
     if (!d || !out) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: null argument");
     *out = nullptr;
     if (n < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: n_devices must be >= 1");
@@ -280,12 +281,13 @@ int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_mul
     for (int r = 0; r < n; ++r) {
         devs[(size_t)r] = devices ? devices[r] : r;
         if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: bad device ordinal");
-        for (int q = 0; q < r; ++q)
+        for (int q = 0; q < r && !one_device; ++q)
             if (devs[(size_t)q] == devs[(size_t)r]) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create: a device is listed twice");
     }
     qln_multi* m = new (std::nothrow) qln_multi();
     if (!m) return fail(QLN_ERR_HIP, "qln_multi_create: out of host memory");
     m->B = d->B;
+    m->one_device = one_device;
     m->shards.resize((size_t)n);
     m->c_off.resize((size_t)d->B);
     auto bail = [&](int code) {
@@ -322,12 +324,24 @@ int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_mul
         m->z_stride = s.dims.z_stride;
     }
     m->comms.assign((size_t)n, nullptr);
-    if (ncclResult_t r = ncclCommInitAll(m->comms.data(), n, devs.data()); r != ncclSuccess) {
-        fail(QLN_ERR_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
-        return bail(QLN_ERR_COMM);
+    if (!one_device) {
+        if (ncclResult_t r = ncclCommInitAll(m->comms.data(), n, devs.data()); r != ncclSuccess) {
+            fail(QLN_ERR_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+            return bail(QLN_ERR_COMM);
+        }
     }
     *out = m;
     return QLN_OK;
+}
+
+int qln_multi_create(const qln_batch_desc* d, int n, const int* devices, qln_multi** out) {
+    return multi_create_impl(d, n, devices, false, out);
+}
+
+int qln_multi_create_on_one_device(const qln_batch_desc* d, int n_shards, int device, qln_multi** out) {
+    if (n_shards < 1) return fail(QLN_ERR_INVALID_ARGUMENT, "qln_multi_create_on_one_device: n_shards must be >= 1");
+    const std::vector<int> devs((size_t)n_shards, device);
+    return multi_create_impl(d, n_shards, devs.data(), true, out);
 }
 
 int qln_multi_num_devices(const qln_multi* m, int* n) {
@@ -471,6 +485,26 @@ int qln_multi_gather(qln_multi* m, uint32_t what, int root) {
     if ((what & QLN_GATHER_F) && !m->g_f) QM_HIP(hipMalloc(reinterpret_cast<void**>(&m->g_f), (size_t)m->B * 8));
     if ((what & QLN_GATHER_VIOL) && !m->g_viol) QM_HIP(hipMalloc(reinterpret_cast<void**>(&m->g_viol), (size_t)m->B * 8));
     if ((what & QLN_GATHER_C) && !m->g_c) QM_HIP(hipMalloc(reinterpret_cast<void**>(&m->g_c), (size_t)std::max<int64_t>(m->c_total, 1) * 8));
+    if (m->one_device) {
+        // n shards on ONE device (RCCL admits one rank per device): the exchange of every send / receive pair is a device
+        // copy on the root's stream, ordered behind the sending shard's stream by an event -- the ordering the pair has
+        // over RCCL (send after the shard's evaluations, receive on the root's stream), the same offsets and counts
+        for (auto& s : m->shards) {
+            const size_t nb = (size_t)(s.hi - s.lo);
+            hipEvent_t ev = nullptr;
+            QM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(ev, s.stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(rs.stream, ev, 0);
+            if (e == hipSuccess && (what & QLN_GATHER_F)) e = hipMemcpyAsync(m->g_f + s.lo, s.f, nb * 8, hipMemcpyDeviceToDevice, rs.stream);
+            if (e == hipSuccess && (what & QLN_GATHER_VIOL)) e = hipMemcpyAsync(m->g_viol + s.lo, s.viol, nb * 8, hipMemcpyDeviceToDevice, rs.stream);
+            if (e == hipSuccess && (what & QLN_GATHER_C) && s.dims.c_total > 0)
+                e = hipMemcpyAsync(m->g_c + s.c_displ, s.c, (size_t)s.dims.c_total * 8, hipMemcpyDeviceToDevice, rs.stream);
+            (void)hipEventDestroy(ev);  // released once the recorded work has completed
+            if (e != hipSuccess) return fail(QLN_ERR_HIP, std::string("qln_multi_gather (one device): ") + hipGetErrorString(e));
+        }
+        m->gathered |= what;
+        return QLN_OK;
+    }
     // every shard sends on its own stream (ordered after its evaluations); the root receives on its stream
     ncclResult_t res = ncclSuccess;
     QM_NCCL(ncclGroupStart());

@@ -39,6 +39,7 @@ SIGNATURES = {
     "qln_comm_max": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "qln_comm_barrier": (C.c_int, [_vp]),
     "qln_multi_create": (C.c_int, [C.POINTER(_lib.QlnBatchDesc), C.c_int, _ip, C.POINTER(_vp)]),
+    "qln_multi_create_on_one_device": (C.c_int, [C.POINTER(_lib.QlnBatchDesc), C.c_int, C.c_int, C.POINTER(_vp)]),
     "qln_multi_destroy": (C.c_int, [_vp]),
     "qln_multi_num_devices": (C.c_int, [_vp, _ip]),
     "qln_multi_shard": (C.c_int, [_vp, C.c_int, _ip, _i64p, _i64p, C.POINTER(_vp), _dpp, _dpp, _dpp, _dpp, _dpp]),
@@ -171,7 +172,9 @@ class MultiNLP:
     HybridNLP, plus `devices` (list of HIP ordinals)."""
 
     def __init__(self, model, obj, init_mode, k_trans, N: int, x0, xf, *, devices, z_stride: int = 0, align: int = 16,
-                 jac_format: str = "dense_blocks"):
+                 jac_format: str = "dense_blocks", one_device: bool = False):
+        """`one_device=True`: the rehearsal of the n > 1 paths on one GPU (qln_multi_create_on_one_device) -- `devices` then
+        lists the SAME ordinal once per shard; no RCCL clique, the gather's exchange is device copies."""
         from .nlp import JAC_FORMATS, n
 
         x0 = np.asarray(x0, dtype=np.float64)
@@ -193,7 +196,12 @@ class MultiNLP:
         d.cost_batch, d.z_stride, d.align, d.jac_format = cost_batch, int(z_stride), int(align), JAC_FORMATS[jac_format]
         devs = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        _lib.check(lib().qln_multi_create(C.byref(d), len(devices), devs, C.byref(h)))
+        if one_device:
+            if len(set(devices)) != 1:
+                raise ValueError("one_device=True: `devices` lists one ordinal, once per shard")
+            _lib.check(lib().qln_multi_create_on_one_device(C.byref(d), len(devices), int(devices[0]), C.byref(h)))
+        else:
+            _lib.check(lib().qln_multi_create(C.byref(d), len(devices), devs, C.byref(h)))
         self._h = h
         self.n_devices = len(devices)
         self.n_nlp = 20 * self.N - 5
