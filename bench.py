@@ -439,8 +439,9 @@ def run_single_process(args):
 
 def multi_gpu_status(n):
     return ("single GPU" if n == 1 else
-            f"N = {n}: this code path had never executed with more than one device before this run (the build pool exposes one "
-            "GPU per box; shard bookkeeping is CPU-tested, the one-shard clique GPU-tested)")
+            f"N = {n}: RCCL between distinct devices had never executed before this run (the build pool exposes one GPU per "
+            "box; the N > 1 control flow of both drivers was rehearsed with shards / ranks on one device, shard bookkeeping is "
+            "CPU-tested, the one-shard clique GPU-tested)")
 
 
 class _GlooComm:
