@@ -255,7 +255,7 @@ def test_gauss_newton_random_shapes_property():
     from hypothesis import given, settings, strategies as st
     from quadruped_landing_amd import HybridNLP, problem_gen as PG
 
-    @settings(max_examples=12, deadline=None)
+    @settings(max_examples=int(__import__("os").environ.get("QLN_FUZZ_EXAMPLES", 12)), deadline=None)
     @given(B=st.integers(1, 6), N=st.integers(2, 100), pad=st.integers(0, 5), align=st.sampled_from([1, 2, 16]),
            scaled=st.booleans(), seed=st.integers(0, 10**6))
     def check(B, N, pad, align, scaled, seed):

@@ -134,7 +134,7 @@ def test_products_random_shapes_and_layouts_property():
     from hypothesis import given, settings, strategies as st
     from quadruped_landing_amd import problem_gen as PG
 
-    @settings(max_examples=15, deadline=None)
+    @settings(max_examples=int(__import__("os").environ.get("QLN_FUZZ_EXAMPLES", 15)), deadline=None)
     @given(B=st.integers(1, 24), N=st.integers(2, 200), pad=st.integers(0, 9), align=st.sampled_from([1, 2, 3, 16, 32]),
            seed=st.integers(0, 10**6))
     def check(B, N, pad, align, seed):
