@@ -1273,7 +1273,7 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
             return launch_cj_t<16, 16, 1, false, true>(p, b_begin, nb, Z, c, vals, flags, stream);
         }
     }
-    // Shipping configuration: T=12 (28.8 KB tile, 5 waves per CU) when the Jacobian is written (below), 40- or 64-knot chunks
+    // Shipping configuration: T=12 (28.8 KB tile; 256 VGPRs + 17 AGPRs => one wave per SIMD, 4 waves per CU) when the Jacobian is written (below), 40- or 64-knot chunks
     // with two waves per SIMD for the constraint-only launch (profiles/r01_variants.txt, r03_dense_floor.txt, r03_c_only_variants.txt).
 #ifdef QLN_TUNING
     // tuning build only (make tuning -> libqln_hip_tuning.so): QLN_VARIANT selects other instantiations for A/B runs
@@ -1285,6 +1285,15 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         case 1: return launch_cj_t<8, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 2: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
         case 3: return launch_cj_t<16, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream);
+        // the shipping tile with the prefetch, register budget of one / two waves per SIMD (4 / 5 waves per CU; two: 104 B of scratch)
+        case 4: return launch_cj_t<12, 64, 1>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 64) ? kDensePrefetchAhead : 0u);
+        case 5: return launch_cj_t<12, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 64) ? kDensePrefetchAhead : 0u);
+        case 6: return launch_cj_t<10, 64, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 64) ? kDensePrefetchAhead : 0u);
+        // 40-knot chunks: 13 staging registers instead of 21 -- the fused instantiation then fits the two-waves-per-SIMD budget
+        case 7: return launch_cj_t<12, 40, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 40) ? kDensePrefetchAhead : 0u);
+        case 8: return launch_cj_t<8, 40, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 40) ? kDensePrefetchAhead : 0u);
+        case 9: return launch_cj_t<16, 40, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 40) ? kDensePrefetchAhead : 0u);
+        case 10: return launch_cj_t<10, 40, 2>(p, b_begin, nb, Z, c, vals, flags, stream, (c && p.N - 1 <= 40) ? kDensePrefetchAhead : 0u);
         default: break;
     }
     if (!vals) switch (variant) {  // constraint-only launch: chunk size / tile (= LDS) / register budget
@@ -1329,7 +1338,10 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
     }
     // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
     if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
-    // dense blocks: a 12-block tile (28.8 KB, 5 waves per CU).  All three tile sizes sit on the launch's floor (profiles/r03_dense_floor.txt);
+    // dense blocks: a 12-block tile (28.8 KB of LDS would admit 5 waves per CU; the fused instantiation with 64-knot chunks takes
+    // 256 VGPRs + 17 AGPRs, i.e. one wave per SIMD = 4 waves per CU.  40-knot chunks fit the two-waves-per-SIMD budget without scratch
+    // -- 5 / 6 / 8 waves per CU with T = 12 / 10 / 8 -- and are no faster: 1.044-1.047 / 1.076-1.078 / 1.070-1.072 ms against
+    // 1.047 ms, same box: more concurrent write fronts cost, profiles/r03_dense_floor.txt).  All tile sizes sit on the launch's floor;
     // on region-placed buffers T = 12 is the fastest by 0.5-1 % (config 3: 1.060-1.063 against 1.069-1.074 ms for T = 16, config 4:
     // 2.155-2.162 against 2.168-2.174 ms; round 1 chose T = 16 on buffers lying in one region)
     // One-chunk problems (N <= 65) prefetch the slice of the workgroup 64 problems ahead on the XCD into L2 (kDensePrefetchAhead):
