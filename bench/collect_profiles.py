@@ -60,8 +60,17 @@ with open(os.path.join(PROF, "ROUNDS.md"), "w") as fh:
              "allocation; PMC traffic per launch from the separate `--pmc` passes of the same round.  Every round is a different box.\n\n"
              "| files `profiles/<prefix>_*` | workload | kernel build | placed: rocprofv3 / HIP events (ms) | plain: rocprofv3 / HIP events (ms) | HBM traffic per launch (GB) |\n|---|---|---|---|---|---|\n")
     f4 = lambda v: "–" if v is None else f"{v:.4f}"
+    gaps = []
     for r in recs:
+        a, b = r.get('kernel_avg_ms_rocprof_placed'), r.get('kernel_avg_ms_hip_events_placed')
+        if a and b and b > 1.05 * a:
+            gaps.append(f"`{r['round']}_{r['key']}_{r['n']}` (placed run: {b:.4f} ms by HIP events against {a:.4f} ms per kernel)")
         fh.write(f"| `{r['round']}_{r['key']}_{r['n']}` | {r['key']} | `{r.get('build_id')}` | {f4(r.get('kernel_avg_ms_rocprof_placed'))} / "
                  f"{f4(r.get('kernel_avg_ms_hip_events_placed'))} | {f4(r.get('kernel_avg_ms_rocprof_plain'))} / {f4(r.get('kernel_avg_ms_hip_events_plain'))} | "
                  f"{r['hbm_bytes_per_launch'] / 1e9:.3f} |\n")
+    if gaps:
+        fh.write("\nSince round 3's `bench.py` the HIP-event figure is ONE pair of events around the K back-to-back launches of the timed region, / K: it "
+                 "contains whatever gaps the host leaves between launches.  Un-profiled there are none (the figure equals the per-kernel average); under "
+                 "`rocprofv3` the host can fall behind its queue, and the figure then exceeds the per-kernel average of the very same dispatches -- a "
+                 "property of the profiled run, not of the kernel: " + "; ".join(gaps) + ".\n")
 print(open(os.path.join(PROF, "ROUNDS.md")).read())
