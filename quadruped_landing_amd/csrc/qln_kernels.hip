@@ -1336,8 +1336,14 @@ hipError_t launch_constraint_jacobian(const BatchParams& p, int32_t b_begin, int
         if ((knots + 39) / 40 == (knots + 63) / 64) return launch_c_only_t<5, 40, 2>(p, b_begin, nb, Z, c, stream);
         return launch_c_only_t<8, 64, 2>(p, b_begin, nb, Z, c, stream);
     }
-    // structural format: 40-knot chunks (22.7 KB of LDS, 2 waves per SIMD; profiles/r01_structural_variants.txt)
-    if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+    // structural format: 40-knot chunks (dynamic LDS sized for the batch, 19.1 KB at config 3; 2 waves per SIMD; profiles/r01_structural_variants.txt)
+    // Horizons that 64-knot chunks cover in fewer passes (N - 1 = 41 .. 64, 81 .. 128, ...) take those: N = 65 0.378 against 0.410 ms
+    // for the same knot points as config 3 (bench/packing_probe.py, profiles/r03_packing_probe.txt)
+    if (p.jac_format == QLN_JAC_FORMAT_STRUCTURAL) {
+        const int knots = p.N - 1;
+        if ((knots + 39) / 40 == (knots + 63) / 64) return launch_cj_t<0, 40, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+        return launch_cj_t<0, 64, 1, true>(p, b_begin, nb, Z, c, vals, flags, stream);
+    }
     // dense blocks: a 12-block tile (28.8 KB of LDS would admit 5 waves per CU; the fused instantiation with 64-knot chunks takes
     // 256 VGPRs + 17 AGPRs, i.e. one wave per SIMD = 4 waves per CU.  40-knot chunks fit the two-waves-per-SIMD budget without scratch
     // -- 5 / 6 / 8 waves per CU with T = 12 / 10 / 8 -- and are no faster: 1.044-1.047 / 1.076-1.078 / 1.070-1.072 ms against
