@@ -361,3 +361,31 @@ def test_every_problem_of_the_full_size_configs_against_the_oracle(B, N, ragged)
         del ref, cg, vg, rc, rv, ok, nzm
     print(f"B={B} N={N}: every problem against the oracle -- {n_eq} entries of c bit-identical, {n_cl} clearance rows differ by <= "
           f"{worst_cl:.2e} relative, f and grad bit-identical, Jacobian entries within {worst_j:.2e}")
+
+
+@pytest.mark.parametrize("fmt", ["dense_blocks", "structural"])
+def test_full_size_one_launch_entry_points_give_the_bits_of_the_separate_ones(fmt):
+    """B = 65 536, N = 40 (BASELINE.json configs[2]), both formats: qln_eval_all (f, grad, c, J from one read of Z) and
+    qln_eval_objective_and_constraint (f, c) return, for every problem, the bits of the fused launch and of the separate
+    objective / gradient kernels (which the test above holds to the oracle problem by problem)."""
+    import torch
+    from quadruped_landing_amd import HybridNLP, problem_gen as PG
+
+    B, N = 65536, 40
+    batch = PG.make_batch(B, N, 14, 1, seed=6)
+    nlp = HybridNLP(batch.model, batch.obj, batch.init_mode, batch.k_trans, batch.N, batch.x0, batch.xf, jac_format=fmt)
+    Z = nlp.upload_Z(batch.Z)
+    nan = float("nan")
+    mk = lambda n: torch.full((n,), nan, dtype=torch.float64, device="cuda")
+    zt, ct, jt = nlp.dims.z_total, nlp.dims.c_total, nlp.dims.j_total
+    c0, v0 = nlp.eval_c_and_jac(Z, mk(ct), mk(jt))
+    f0, g0 = nlp.eval_f(Z), nlp.grad_f(Z, mk(zt))
+    f1, g1, c1, v1 = nlp.eval_all(Z, mk(B), mk(zt), mk(ct), mk(jt))
+    torch.cuda.synchronize()
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert eq(c0, c1) and eq(v0, v1) and eq(f0, f1) and eq(g0, g1)
+    del v1, g1, c1, f1
+    f2, c2 = nlp.eval_f_and_c(Z, mk(B), mk(ct))
+    torch.cuda.synchronize()
+    assert eq(f0, f2) and eq(c0, c2)
+    assert not torch.isnan(f0).any()
