@@ -21,6 +21,13 @@ def _fuzz_examples(default):
     return int(os.environ.get("QLN_FUZZ_EXAMPLES", default))
 
 
+def _fuzz_fixed():
+    """the suite's own run draws the same examples every time (a red suite must be reproducible); a campaign draws fresh ones"""
+    import os
+
+    return "QLN_FUZZ_EXAMPLES" not in os.environ
+
+
 def _gpu_eval(batch, **kw):
     import torch
     from quadruped_landing_amd import HybridNLP
@@ -392,7 +399,7 @@ def test_every_entry_point_gives_the_same_bits_property():
 
     ran = [0, 0]
 
-    @settings(max_examples=_fuzz_examples(12), deadline=None)
+    @settings(max_examples=_fuzz_examples(12), deadline=None, derandomize=_fuzz_fixed())
     @given(B=st.one_of(st.integers(1, 60), st.integers(250, 700)), N=st.integers(2, 140), pad=st.integers(0, 5),
            align=st.sampled_from([1, 2, 16]), fmt=st.sampled_from(["dense_blocks", "structural"]), shared=st.booleans(),
            seed=st.integers(0, 10**6))
@@ -443,7 +450,7 @@ def test_extreme_magnitudes_value_path_property():
 
     ran = [0]
 
-    @settings(max_examples=_fuzz_examples(10), deadline=None)
+    @settings(max_examples=_fuzz_examples(10), deadline=None, derandomize=_fuzz_fixed())
     @given(B=st.integers(1, 24), N=st.integers(2, 90), fmt=st.sampled_from(["dense_blocks", "structural"]),
            frac=st.sampled_from([0.002, 0.02, 0.3, 1.0]), lo=st.sampled_from([-320, -300, -30]), hi=st.sampled_from([30, 150, 300]),
            seed=st.integers(0, 10**6))

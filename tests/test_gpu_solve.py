@@ -395,7 +395,7 @@ def test_solver_invariants_for_random_shapes_property():
 
     ran = [0, 0]
 
-    @settings(max_examples=int(os.environ.get("QLN_FUZZ_EXAMPLES", 8)), deadline=None)
+    @settings(max_examples=int(os.environ.get("QLN_FUZZ_EXAMPLES", 8)), deadline=None, derandomize="QLN_FUZZ_EXAMPLES" not in os.environ)
     @given(B=st.integers(1, 12), N=st.integers(2, 130), ragged=st.booleans(), noise=st.sampled_from([0.0, 0.01, 0.05]),
            seed=st.integers(0, 10**6))
     def check(B, N, ragged, noise, seed):
